@@ -1,0 +1,91 @@
+"""Pin the CPU oracle (oracle/sr3_oracle.py) against vectors produced by the reference itself
+(oracle/make_golden.py, committed under tests/golden/).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sr3_oracle as O
+from helpers import DESCS, SCHEDS, CONDITIONAL, load_golden
+
+NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam']
+TOL = 2e-6     # same torch CPU ops in a different call order; observed ~1e-7
+
+
+def close(a, b, tol=TOL):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    d = np.abs(a - b).max()
+    assert d <= tol * max(1.0, np.abs(b).max()), d
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_unet_forward_and_taps(name):
+    g, sd = load_golden(name)
+    taps = {}
+    x = torch.from_numpy(g['unet/x']); t = torch.from_numpy(g['unet/time'])
+    with torch.no_grad():
+        eps = O.unet_forward(sd, DESCS[name], x, t, taps=taps)
+    close(eps.numpy(), g['unet/eps'])
+    n = 0
+    for k, v in g.items():
+        if k.startswith('unet/tap/'):
+            close(taps[k[len('unet/tap/'):]].numpy(), v)
+            n += 1
+    assert n == len(taps) and n > 4
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_schedule_tables(name):
+    g, sd = load_golden(name)
+    tab = O.schedule_tables(SCHEDS[name])
+    for k in ('betas', 'alphas_cumprod', 'alphas_cumprod_prev', 'sqrt_alphas_cumprod',
+              'sqrt_one_minus_alphas_cumprod', 'log_one_minus_alphas_cumprod', 'sqrt_recip_alphas_cumprod',
+              'sqrt_recipm1_alphas_cumprod', 'posterior_variance', 'posterior_log_variance_clipped',
+              'posterior_mean_coef1', 'posterior_mean_coef2'):
+        assert np.array_equal(tab[k], g['sd/' + k]), k
+    if DESCS[name]['variant'] == 'sr3':
+        assert np.array_equal(tab['sqrt_alphas_cumprod_prev'], g['meta/host_sqrt_alphas_cumprod_prev'])
+    assert tab['num_timesteps'] == int(g['meta/T'])
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_p_sample_steps_and_loop(name):
+    g, sd = load_golden(name)
+    d = DESCS[name]; tab = O.schedule_tables(SCHEDS[name]); cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']); zs = torch.from_numpy(g['loop/zs'])
+    xs = torch.from_numpy(g['step/x'])
+    T = tab['num_timesteps']
+    with torch.no_grad():
+        for t in sorted({T - 1, T // 2, 0}):
+            r = O.p_sample(sd, d, tab, xs, t, zs[t], condition_x=sr if cond else None)
+            close(r.numpy(), g['step/%d' % t])
+        x_T = torch.from_numpy(g['loop/x_T'])
+        for cont in (True, False):
+            r = O.p_sample_loop(sd, d, tab, sr, x_T, zs, conditional=cond, continous=cont)
+            close(r.numpy(), g['loop/ret_continous' if cont else 'loop/ret_last'], 5e-6)
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_p_losses(name):
+    g, sd = load_golden(name)
+    d = DESCS[name]; tab = O.schedule_tables(SCHEDS[name]); cond = CONDITIONAL[name]
+    hr = torch.from_numpy(g['loop/hr']); sr = torch.from_numpy(g['loop/sr']); z = torch.from_numpy(g['train/z'])
+    with torch.no_grad():
+        if d['variant'] == 'sr3':
+            loss = O.p_losses_sr3(sd, d, hr, sr, torch.from_numpy(g['train/gamma']), z, conditional=cond)
+        else:
+            loss = O.p_losses_ddpm(sd, d, tab, hr, sr, torch.from_numpy(g['train/t']), z, conditional=cond)
+    assert abs(float(loss) - float(g['train/loss_sum'])) <= 1e-5 * abs(float(g['train/loss_sum']))
+    assert abs(float(loss) / hr.numel() - float(g['train/l_pix'])) <= 1e-5 * abs(float(g['train/l_pix']))
+
+
+def test_topology_matches_reference_counts():
+    """SR3 16->128 has 27 resnet blocks, 6 attention cores, 4 down / 4 up."""
+    d = dict(variant='sr3', in_channel=6, out_channel=3, inner_channel=64, norm_groups=32,
+             channel_mults=[1, 2, 4, 8, 8], attn_res=[16], res_blocks=2, image_size=128)
+    topo = O.unet_topology(d)
+    layers = topo['downs'] + topo['mid'] + topo['ups']
+    assert sum(l['kind'] == 'res' for l in layers) == 27
+    assert sum(l['kind'] == 'res' and l['attn'] for l in layers) == 6
+    assert sum(l['kind'] == 'down' for l in layers) == 4 and sum(l['kind'] == 'up' for l in layers) == 4
+    assert [l['cin'] for l in topo['ups'] if l['kind'] == 'res'][:4] == [1024, 1024, 1024, 1024]
