@@ -1,0 +1,379 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (157 TF peak; bitwise an fmaf chain, see MI355X_MICROARCH.md).
+//
+// Replaces, on the reference hot path, every `nn.Conv2d` call of the UNet together with the
+// GroupNorm -> Swish prologue of `Block` (model/sr3_modules/unet.py:80-91), the FiLM add
+// (:34-50, :108), the residual add (:110, :142), the nearest upsample (:58-65), the stride-2
+// Downsample (:68-74) and the skip `torch.cat` (:255) -- none of which is materialised.
+//
+// GEMM view:  out[m][n] = sum_k A[m][k] * W[n][k],  m = (b, oh, ow), n = cout, k = (tap, cin).
+// Layout: activations NHWC (k contiguous for a fixed tap), weights OHWI ([n][tap][cin]), so both
+// operands are "k-contiguous rows": a float4 global load lands as one ds_write_b128 into an
+// LDS tile [rows][32 + 4 pad]; fragments come back as one ds_read_b128 per 4 MFMA k-steps
+// (the lane's 4 consecutive k; lanes 0-31 / 32-63 take k-quads 0 / 1 of each 8-k group, which
+// is a permutation of the k order shared by A and B, so the sum is unchanged).
+// Block = 256 threads = 2x2 waves, tile BM x BN, k-step 32 channels of one filter tap,
+// double-buffered LDS with register staging (global -> VGPR -> [GN/SiLU] -> LDS), one barrier
+// per k-step.  Split-K writes fp32 slabs that a second kernel reduces (deterministic).
+#include "sr3_common.h"
+
+namespace sr3 {
+
+__device__ __forceinline__ float silu_f(float v) {
+  // x * sigmoid(x); exp is the accurate libm one, reciprocal is v_rcp_f32 (1 ulp)
+  return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
+}
+
+template <int BM, int BN, int TAPS>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
+  constexpr int BK = 32, LDK = 36;
+  constexpr int AR = BM / 32, BR = BN / 32;  // loader rows per thread
+  constexpr int WM = BM / 2, WN = BN / 2;    // wave tile, 2x2 waves
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int STAGE = (BM + BN) * LDK;
+  extern __shared__ f32x4 smem_v[];
+  float* smem = reinterpret_cast<float*>(smem_v);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = tid & 7, lrow = tid >> 3;
+  const int Cin = p.C0 + p.C1;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
+  constexpr int PAD = (TAPS == 9) ? 1 : 0;
+  const int nchunks = (Cin + BK - 1) / BK;
+  const int total = nchunks * TAPS;
+  const int per = (total + p.ksplit - 1) / p.ksplit;
+  const int it0 = blockIdx.y * per;
+  const int it1 = min(total, it0 + per);
+
+  // ---- per-thread loader rows -------------------------------------------------------------
+  int rb[AR], rih[AR], riw[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = tile_m * BM + lrow + 32 * i;
+    if (m < M) {
+      const int b = m / HoWo;
+      const int rem = m - b * HoWo;
+      const int oh = rem / p.Wo;
+      const int ow = rem - oh * p.Wo;
+      rb[i] = b;
+      rih[i] = oh * p.stride - PAD;
+      riw[i] = ow * p.stride - PAD;
+    } else {
+      rb[i] = -1; rih[i] = 0; riw[i] = 0;
+    }
+  }
+
+  f32x4 ra[AR], rw[BR], ssa[AR], ssb[AR];
+  bool aok[AR];
+  int ss_chunk = -1;
+
+  auto load_global = [&](int it) {
+    const int chunk = it / TAPS;
+    const int tap = it - chunk * TAPS;
+    const int fr = (TAPS == 9) ? tap / 3 : 0;
+    const int fs = (TAPS == 9) ? tap - fr * 3 : 0;
+    const int c = chunk * BK + kq * 4;
+    const bool cvalid = c < Cin;
+    const float* sp = p.src0;
+    int sC = p.C0, cs = c;
+    if (c >= p.C0) { sp = p.src1; sC = p.C1; cs = c - p.C0; }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int ih = rih[i] + fr, iw = riw[i] + fs;
+      const bool ok = cvalid && rb[i] >= 0 && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+      aok[i] = ok;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const size_t pix = ((size_t)rb[i] * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+        v = *reinterpret_cast<const f32x4*>(sp + pix * sC + cs);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int n = tile_n * BN + lrow + 32 * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cvalid && n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)n * TAPS + tap) * Cin + c);
+      rw[j] = v;
+    }
+    if (p.act != 0 && chunk != ss_chunk) {
+      ss_chunk = chunk;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        if (cvalid && rb[i] >= 0) {
+          const float* q = p.ss + ((size_t)rb[i] * Cin + c) * 2;
+          ssa[i] = *reinterpret_cast<const f32x4*>(q);
+          ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+      }
+    }
+  };
+
+  auto store_lds = [&](int stage) {
+    float* A = smem + stage * STAGE;
+    float* Bw = A + BM * LDK;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      f32x4 v = ra[i];
+      if (p.act != 0 && aok[i]) {
+        v.x = fmaf(v.x, ssa[i].x, ssa[i].y);
+        v.y = fmaf(v.y, ssa[i].z, ssa[i].w);
+        v.z = fmaf(v.z, ssb[i].x, ssb[i].y);
+        v.w = fmaf(v.w, ssb[i].z, ssb[i].w);
+        if (p.act == 2) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+      }
+      *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = rw[j];
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave_m = wave >> 1, wave_n = wave & 1;
+  const int arow = wave_m * WM + (lane & 31);
+  const int brow = wave_n * WN + (lane & 31);
+  const int kh = (lane >> 5) * 4;
+
+  auto compute = [&](int stage) {
+    const float* A = smem + stage * STAGE;
+    const float* Bw = A + BM * LDK;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(&A[(arow + 32 * i) * LDK + kk * 8 + kh]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bw[(brow + 32 * j) * LDK + kk * 8 + kh]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (it0 < it1) {
+    load_global(it0);
+    store_lds(0);
+    __syncthreads();
+    for (int it = it0; it < it1; ++it) {
+      const int cur = (it - it0) & 1;
+      const bool more = it + 1 < it1;
+      if (more) load_global(it + 1);
+      compute(cur);
+      if (more) store_lds(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  // D layout of the 32x32 MFMA: reg r of lane l -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+  // Rows are walked in groups of 8 (g = r>>2): when Ho*Wo % 8 == 0 a group never straddles an
+  // image, so the image index (FiLM row, statistics bucket) is wave-uniform per group.
+  const bool direct = (p.ksplit == 1);
+  const bool grp_uniform = (HoWo & 7) == 0;
+  const bool do_stat = direct && p.ostat != nullptr;   // host guarantees grp_uniform when set
+  float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * M * p.Cout;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = tile_n * BN + wave_n * WN + 32 * j + (lane & 31);
+    const bool nok = n < p.Cout;
+    float bn = 0.f;
+    if (direct && nok && p.bias) bn = p.bias[n];
+    double s1 = 0.0, s2 = 0.0;   // fused output statistics: column sums over this lane's rows
+    int sb = -1;
+    auto flush = [&]() {
+      if (sb >= 0) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lane < 32 && nok) {
+          atomicAdd(&p.ostat[((size_t)sb * p.Cout + n) * 2], s1);
+          atomicAdd(&p.ostat[((size_t)sb * p.Cout + n) * 2 + 1], s2);
+        }
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int mbase = tile_m * BM + wave_m * WM + 32 * i + 8 * g;   // wave-uniform
+        const int bg = mbase / HoWo;
+        if (do_stat && mbase < M && bg != sb) { flush(); sb = bg; s1 = 0.0; s2 = 0.0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = mbase + e + 4 * (lane >> 5);
+          if (m < M && nok) {
+            float v = acc[i][j][g * 4 + e];
+            if (direct) {
+              const int b = grp_uniform ? bg : m / HoWo;
+              v += bn;
+              if (p.film) v += p.film[(size_t)b * p.film_stride + n];
+              if (p.res0)
+                v += (n < p.RC0) ? p.res0[(size_t)m * p.RC0 + n] : p.res1[(size_t)m * p.RC1 + (n - p.RC0)];
+              if (do_stat) { const double dv = (double)v; s1 += dv; s2 += dv * dv; }
+            }
+            dst[(size_t)m * p.Cout + n] = v;
+          }
+        }
+      }
+    }
+    if (do_stat) flush();
+  }
+}
+
+// ---- split-K reduction + epilogue -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p) {
+  const int HoWo = p.Ho * p.Wo;
+  const size_t M = (size_t)p.B * HoWo;
+  const int nq = p.Cout >> 2;
+  const size_t total = M * nq;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = idx / nq;
+    const int n = (int)(idx - m * nq) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.ksplit; ++s)
+      v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    const int b = (int)(m / HoWo);
+    if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
+    if (p.res0) {
+      if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + m * p.RC0 + n);
+      else v += *reinterpret_cast<const f32x4*>(p.res1 + m * p.RC1 + (n - p.RC0));
+    }
+    *reinterpret_cast<f32x4*>(p.out + m * p.Cout + n) = v;
+    if (p.ostat) {
+      double* o = p.ostat + ((size_t)b * p.Cout + n) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double dv = (double)v[e];
+        atomicAdd(o + 2 * e, dv);
+        atomicAdd(o + 2 * e + 1, dv * dv);
+      }
+    }
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+namespace {
+struct TileCfg { int bm, bn; };
+const TileCfg kCfgs[5] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <int BM, int BN, int TAPS>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * (BM + BN) * 36 * 4;
+  auto kern = k_conv_igemm<BM, BN, TAPS>;
+  if (!attr_set) {
+    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int M = p.B * p.Ho * p.Wo;
+  dim3 grid(cdiv(M, BM) * cdiv(p.Cout, BN), p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  SR3_LAUNCH_CHECK("k_conv_igemm");
+  return SR3_OK;
+}
+}  // namespace
+
+void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
+  const int M = p.B * p.Ho * p.Wo;
+  const int Cin = p.C0 + p.C1;
+  const int taps = p.ksize * p.ksize;
+  const int total = cdiv(Cin, 32) * taps;
+  if (tile_cfg == 0) {
+    // largest tile that still gives >= ~2 workgroups per CU; fall back to the smallest tile.
+    const int order_wide[3] = {1, 2, 3};
+    const int order_narrow[2] = {2, 3};
+    const int* order = p.Cout > 64 ? order_wide : order_narrow;
+    const int norder = p.Cout > 64 ? 3 : 2;
+    tile_cfg = order[norder - 1];
+    for (int k = 0; k < norder; ++k) {
+      const TileCfg c = kCfgs[order[k]];
+      if ((long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn) >= 448) { tile_cfg = order[k]; break; }
+    }
+  }
+  if (ksplit == 0) {
+    const TileCfg c = kCfgs[tile_cfg];
+    const long tiles = (long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn);
+    int ks = 1;
+    if (tiles < 384) {
+      ks = (int)((512 + tiles - 1) / tiles);
+      const int max_by_k = total / 6 > 1 ? total / 6 : 1;
+      if (ks > max_by_k) ks = max_by_k;
+      if (ks > 16) ks = 16;
+    }
+    // no empty splits
+    while (ks > 1 && (long)(ks - 1) * cdiv(total, ks) >= total) --ks;
+    ksplit = ks;
+  }
+}
+
+size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit) {
+  conv_pick(p, tile_cfg, ksplit);
+  if (ksplit <= 1) return 0;
+  return (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout * sizeof(float);
+}
+
+int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch, size_t scratch_bytes,
+                 hipStream_t st) {
+  ConvParams p = pin;
+  const int Cin = p.C0 + p.C1;
+  if ((p.C0 & 3) || (p.C1 & 3) || (p.Cout & 3)) { set_error("conv: channel counts must be multiples of 4 (C0=%d C1=%d Cout=%d)", p.C0, p.C1, p.Cout); return SR3_E_UNSUPPORTED; }
+  if (p.ksize != 1 && p.ksize != 3) { set_error("conv: ksize %d unsupported", p.ksize); return SR3_E_UNSUPPORTED; }
+  if (p.stride != 1 && p.stride != 2) { set_error("conv: stride %d unsupported", p.stride); return SR3_E_UNSUPPORTED; }
+  if (p.act != 0 && !p.ss) { set_error("conv: act needs ss"); return SR3_E_BADARG; }
+  if (p.C1 > 0 && !p.src1) { set_error("conv: C1 > 0 needs src1"); return SR3_E_BADARG; }
+  if (p.res0 && p.RC0 + p.RC1 != p.Cout) { set_error("conv: residual channels %d+%d != Cout %d", p.RC0, p.RC1, p.Cout); return SR3_E_BADARG; }
+  const int pad = p.ksize / 2;
+  const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
+  if ((Hi + 2 * pad - p.ksize) / p.stride + 1 != p.Ho || (Wi + 2 * pad - p.ksize) / p.stride + 1 != p.Wo) {
+    set_error("conv: output dims %dx%d inconsistent with input %dx%d k%d s%d", p.Ho, p.Wo, Hi, Wi, p.ksize, p.stride);
+    return SR3_E_BADARG;
+  }
+  (void)Cin;
+  conv_pick(p, tile_cfg, ksplit);
+  p.ksplit = ksplit;
+  if (ksplit > 1) {
+    const size_t need = (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout * sizeof(float);
+    if (!scratch || scratch_bytes < need) { set_error("conv: split-K scratch too small (%zu < %zu)", scratch_bytes, need); return SR3_E_NOMEM; }
+    p.partial = scratch;
+  }
+  int rc;
+  const bool k3 = p.ksize == 3;
+  switch (tile_cfg) {
+    case 1: rc = k3 ? launch_conv<128, 128, 9>(p, st) : launch_conv<128, 128, 1>(p, st); break;
+    case 2: rc = k3 ? launch_conv<128, 64, 9>(p, st) : launch_conv<128, 64, 1>(p, st); break;
+    case 3: rc = k3 ? launch_conv<64, 64, 9>(p, st) : launch_conv<64, 64, 1>(p, st); break;
+    case 4: rc = k3 ? launch_conv<64, 128, 9>(p, st) : launch_conv<64, 128, 1>(p, st); break;
+    default: set_error("conv: bad tile_cfg %d", tile_cfg); return SR3_E_BADARG;
+  }
+  if (rc) return rc;
+  if (ksplit > 1) {
+    const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.Cout >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+    SR3_LAUNCH_CHECK("k_splitk_reduce");
+  }
+  return SR3_OK;
+}
+
+}  // namespace sr3

@@ -1,0 +1,782 @@
+// UNet plan: topology, parameter arena, activation plan and the forward driver.
+//
+// Mirrors UNet.__init__ / UNet.forward of the reference (model/sr3_modules/unet.py:162-259,
+// model/ddpm_modules/unet.py:148-243) as a static op list over the HIP kernels of this library.
+// Nothing here is a translation of the reference modules: the forward is compiled once per batch
+// size into a flat list of kernel launches over a liveness-planned NHWC workspace.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sr3_mi355x.h"
+#include "sr3_common.h"
+
+namespace sr3 {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  (void)hipGetLastError();
+  return (int)e > 0 ? (int)e : 1;
+}
+const char* last_error() { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// plan data
+// ---------------------------------------------------------------------------------------------
+struct Tensor {
+  size_t off = 0;       // byte offset in the workspace
+  size_t bytes = 0;
+  int C = 0, H = 0, W = 0;
+  size_t stat_off = 0;  // byte offset of [B][C][2] doubles
+  bool stats_done = false;
+  bool valid = false;
+};
+
+struct ResLayer {
+  std::string name;     // e.g. "downs.1"
+  int cin, cout, skip;  // cin includes skip
+  bool attn;
+  int film_off;         // row offset in the FiLM table
+  size_t gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, rc_w, rc_b;
+  bool has_rc;
+  size_t an_w, an_b, qkv_w, ao_w, ao_b;
+};
+
+struct Layer {
+  int kind;  // 0 conv_in, 1 res, 2 down, 3 up
+  std::string name;
+  int cin, cout;
+  size_t w, b;  // conv_in / down / up
+  ResLayer res;
+};
+
+enum OpKind { OP_MEMSET, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_ATTN, OP_CONV_OUT };
+
+struct Op {
+  OpKind kind;
+  // generic offsets (bytes into workspace unless noted)
+  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+  size_t p0 = 0, p1 = 0, p2 = 0;   // float offsets into the parameter arena
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
+  bool has_src1 = false, has_bias = false, has_film = false, has_res = false, has_res1 = false, has_ostat = false,
+       has_st1 = false;
+  ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
+  int tile_cfg = 0, ksplit = 0;
+};
+
+struct Tap { std::string name; size_t off; int C, H, W; };
+
+}  // namespace sr3
+
+using namespace sr3;
+
+struct sr3_plan {
+  sr3_unet_desc d;
+  std::vector<sr3_param_info> params;
+  std::map<std::string, int> pindex;
+  size_t param_floats = 0;
+  int F = 0;
+  size_t film_w = 0, film_b = 0;
+  size_t emb_w1 = 0, emb_b1 = 0, emb_w2 = 0, emb_b2 = 0;
+  std::vector<Layer> downs, mid, ups;
+  size_t fin_gn_w = 0, fin_gn_b = 0, fin_w = 0, fin_b = 0;
+  int fin_cin = 0, out_ch = 0;
+  // options
+  int fuse_stats = 0, tile_cfg = 0, ksplit = 0, keep_all = 0;
+  // compiled forward
+  int built_batch = -1;
+  int built_cond = -1;
+  std::vector<Op> ops;
+  std::vector<Tap> taps;
+  size_t ws_bytes = 0;
+  size_t stats_off = 0, stats_bytes = 0, ss_off = 0, temb_off = 0, film_off = 0, scratch_off = 0, scratch_bytes = 0;
+  double flops = 0;
+};
+
+namespace sr3 {
+
+// ---------------------------------------------------------------------------------------------
+// parameter table
+// ---------------------------------------------------------------------------------------------
+static size_t add_param(sr3_plan* P, const std::string& name, int ndim, const int* shape, int pack, size_t* cursor) {
+  sr3_param_info pi;
+  memset(&pi, 0, sizeof(pi));
+  snprintf(pi.name, sizeof(pi.name), "%s", name.c_str());
+  pi.ndim = ndim;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { pi.shape[i] = shape[i]; n *= (size_t)shape[i]; }
+  pi.pack = pack;
+  pi.numel = n;
+  *cursor = (*cursor + 3) & ~(size_t)3;   // 16-byte alignment of every tensor
+  pi.offset = *cursor;
+  *cursor += n;
+  P->pindex[name] = (int)P->params.size();
+  P->params.push_back(pi);
+  return pi.offset;
+}
+static size_t add_vec(sr3_plan* P, const std::string& name, int n, size_t* cur) {
+  int s[1] = {n};
+  return add_param(P, name, 1, s, 0, cur);
+}
+static size_t add_mat(sr3_plan* P, const std::string& name, int o, int i, size_t* cur) {
+  int s[2] = {o, i};
+  return add_param(P, name, 2, s, 0, cur);
+}
+static size_t add_conv(sr3_plan* P, const std::string& name, int o, int i, int k, size_t* cur) {
+  int s[4] = {o, i, k, k};
+  return add_param(P, name, 4, s, k == 1 ? 0 : 1, cur);
+}
+
+static bool in_list(const int* v, int n, int x) {
+  for (int i = 0; i < n; ++i) if (v[i] == x) return true;
+  return false;
+}
+
+static int build_structure(sr3_plan* P) {
+  const sr3_unet_desc& d = P->d;
+  const int inner = d.inner_channel;
+  const bool ddpm = d.variant == SR3_VARIANT_DDPM;
+  if (inner <= 0 || (inner & 3)) { set_error("inner_channel must be a positive multiple of 4 (got %d)", inner); return SR3_E_UNSUPPORTED; }
+  if (d.n_mults < 1 || d.n_mults > 8 || d.n_attn_res < 0 || d.n_attn_res > 8) { set_error("bad n_mults/n_attn_res"); return SR3_E_BADARG; }
+  if (d.norm_groups <= 0) { set_error("norm_groups must be > 0"); return SR3_E_BADARG; }
+  if (d.in_channel <= 0 || d.in_channel > 16) { set_error("in_channel %d unsupported", d.in_channel); return SR3_E_UNSUPPORTED; }
+  const int out_ch = d.out_channel > 0 ? d.out_channel : d.in_channel;
+  if (out_ch > 4) { set_error("out_channel %d > 4 unsupported", out_ch); return SR3_E_UNSUPPORTED; }
+  if ((d.image_size >> (d.n_mults - 1)) < 1 || (d.image_size & ((1 << (d.n_mults - 1)) - 1))) {
+    set_error("image_size %d not divisible by 2^%d", d.image_size, d.n_mults - 1);
+    return SR3_E_BADARG;
+  }
+  P->out_ch = out_ch;
+
+  // ---- pass 1: topology (same walk as UNet.__init__) ----
+  struct Proto { int kind; int cin, cout, skip; bool attn; };
+  std::vector<Proto> pd, pm, pu;
+  std::vector<int> feat;
+  int pre = inner, now_res = d.image_size;
+  feat.push_back(pre);
+  pd.push_back({0, d.in_channel, inner, 0, false});
+  for (int ind = 0; ind < d.n_mults; ++ind) {
+    const bool is_last = ind == d.n_mults - 1;
+    const bool use_attn = in_list(d.attn_res, d.n_attn_res, now_res);
+    const int cm = inner * d.channel_mults[ind];
+    for (int r = 0; r < d.res_blocks; ++r) {
+      pd.push_back({1, pre, cm, 0, use_attn});
+      feat.push_back(cm);
+      pre = cm;
+    }
+    if (!is_last) {
+      pd.push_back({2, pre, pre, 0, false});
+      feat.push_back(pre);
+      now_res /= 2;
+    }
+  }
+  pm.push_back({1, pre, pre, 0, true});
+  pm.push_back({1, pre, pre, 0, false});
+  for (int ind = d.n_mults - 1; ind >= 0; --ind) {
+    const bool is_last = ind < 1;
+    const bool use_attn = in_list(d.attn_res, d.n_attn_res, now_res);
+    const int cm = inner * d.channel_mults[ind];
+    for (int r = 0; r < d.res_blocks + 1; ++r) {
+      const int skip = feat.back();
+      feat.pop_back();
+      pu.push_back({1, pre + skip, cm, skip, use_attn});
+      pre = cm;
+    }
+    if (!is_last) {
+      pu.push_back({3, pre, pre, 0, false});
+      now_res *= 2;
+    }
+  }
+  P->fin_cin = pre;
+
+  // ---- pass 2: arena.  FiLM projections first (contiguous => one GEMV for all blocks) ----
+  size_t cur = 0;
+  int F = 0;
+  auto count_f = [&](const std::vector<Proto>& v) { for (auto& p : v) if (p.kind == 1) F += p.cout; };
+  count_f(pd); count_f(pm); count_f(pu);
+  P->F = F;
+  P->film_w = cur; cur += (size_t)F * inner;
+  cur = (cur + 3) & ~(size_t)3;
+  P->film_b = cur; cur += (size_t)F;
+  int frow = 0;
+
+  const char* emb = ddpm ? "time_mlp" : "noise_level_mlp";
+  P->emb_w1 = add_mat(P, std::string(emb) + ".1.weight", 4 * inner, inner, &cur);
+  P->emb_b1 = add_vec(P, std::string(emb) + ".1.bias", 4 * inner, &cur);
+  P->emb_w2 = add_mat(P, std::string(emb) + ".3.weight", inner, 4 * inner, &cur);
+  P->emb_b2 = add_vec(P, std::string(emb) + ".3.bias", inner, &cur);
+
+  auto emit = [&](const std::vector<Proto>& protos, const char* grp, std::vector<Layer>& out) {
+    for (size_t i = 0; i < protos.size(); ++i) {
+      const Proto& pr = protos[i];
+      Layer L;
+      L.kind = pr.kind;
+      L.cin = pr.cin;
+      L.cout = pr.cout;
+      char nm[64];
+      snprintf(nm, sizeof(nm), "%s.%zu", grp, i);
+      L.name = nm;
+      L.w = L.b = 0;
+      std::string n = nm;
+      if (pr.kind == 0) {
+        L.w = add_conv(P, n + ".weight", pr.cout, pr.cin, 3, &cur);
+        L.b = add_vec(P, n + ".bias", pr.cout, &cur);
+      } else if (pr.kind == 2 || pr.kind == 3) {
+        L.w = add_conv(P, n + ".conv.weight", pr.cout, pr.cin, 3, &cur);
+        L.b = add_vec(P, n + ".conv.bias", pr.cout, &cur);
+      } else {
+        ResLayer& R = L.res;
+        R.name = n;
+        R.cin = pr.cin; R.cout = pr.cout; R.skip = pr.skip; R.attn = pr.attn;
+        R.film_off = frow;
+        std::string rb = n + ".res_block";
+        // FiLM rows live in the contiguous block; the table entries point into it
+        {
+          sr3_param_info pi;
+          memset(&pi, 0, sizeof(pi));
+          std::string wn = rb + (ddpm ? ".mlp.1.weight" : ".noise_func.noise_func.0.weight");
+          std::string bn = rb + (ddpm ? ".mlp.1.bias" : ".noise_func.noise_func.0.bias");
+          snprintf(pi.name, sizeof(pi.name), "%s", wn.c_str());
+          pi.ndim = 2; pi.shape[0] = pr.cout; pi.shape[1] = inner; pi.pack = 0;
+          pi.numel = (size_t)pr.cout * inner; pi.offset = P->film_w + (size_t)frow * inner;
+          P->pindex[wn] = (int)P->params.size(); P->params.push_back(pi);
+          memset(&pi, 0, sizeof(pi));
+          snprintf(pi.name, sizeof(pi.name), "%s", bn.c_str());
+          pi.ndim = 1; pi.shape[0] = pr.cout; pi.pack = 0; pi.numel = (size_t)pr.cout; pi.offset = P->film_b + frow;
+          P->pindex[bn] = (int)P->params.size(); P->params.push_back(pi);
+        }
+        frow += pr.cout;
+        R.gn1_w = add_vec(P, rb + ".block1.block.0.weight", pr.cin, &cur);
+        R.gn1_b = add_vec(P, rb + ".block1.block.0.bias", pr.cin, &cur);
+        R.c1_w = add_conv(P, rb + ".block1.block.3.weight", pr.cout, pr.cin, 3, &cur);
+        R.c1_b = add_vec(P, rb + ".block1.block.3.bias", pr.cout, &cur);
+        R.gn2_w = add_vec(P, rb + ".block2.block.0.weight", pr.cout, &cur);
+        R.gn2_b = add_vec(P, rb + ".block2.block.0.bias", pr.cout, &cur);
+        R.c2_w = add_conv(P, rb + ".block2.block.3.weight", pr.cout, pr.cout, 3, &cur);
+        R.c2_b = add_vec(P, rb + ".block2.block.3.bias", pr.cout, &cur);
+        R.has_rc = pr.cin != pr.cout;
+        R.rc_w = R.rc_b = 0;
+        if (R.has_rc) {
+          R.rc_w = add_conv(P, rb + ".res_conv.weight", pr.cout, pr.cin, 1, &cur);
+          R.rc_b = add_vec(P, rb + ".res_conv.bias", pr.cout, &cur);
+        }
+        R.an_w = R.an_b = R.qkv_w = R.ao_w = R.ao_b = 0;
+        if (pr.attn) {
+          std::string at = n + ".attn";
+          R.an_w = add_vec(P, at + ".norm.weight", pr.cout, &cur);
+          R.an_b = add_vec(P, at + ".norm.bias", pr.cout, &cur);
+          R.qkv_w = add_conv(P, at + ".qkv.weight", 3 * pr.cout, pr.cout, 1, &cur);
+          R.ao_w = add_conv(P, at + ".out.weight", pr.cout, pr.cout, 1, &cur);
+          R.ao_b = add_vec(P, at + ".out.bias", pr.cout, &cur);
+        }
+      }
+      out.push_back(L);
+    }
+  };
+  emit(pd, "downs", P->downs);
+  emit(pm, "mid", P->mid);
+  emit(pu, "ups", P->ups);
+  P->fin_gn_w = add_vec(P, "final_conv.block.0.weight", P->fin_cin, &cur);
+  P->fin_gn_b = add_vec(P, "final_conv.block.0.bias", P->fin_cin, &cur);
+  P->fin_w = add_conv(P, "final_conv.block.3.weight", out_ch, P->fin_cin, 3, &cur);
+  P->fin_b = add_vec(P, "final_conv.block.3.bias", out_ch, &cur);
+  P->param_floats = (cur + 3) & ~(size_t)3;
+
+  // every GroupNorm must divide
+  auto chk = [&](int c) { return c % d.norm_groups == 0; };
+  bool ok = chk(P->fin_cin);
+  for (auto* v : {&P->downs, &P->mid, &P->ups})
+    for (auto& L : *v)
+      if (L.kind == 1) ok = ok && chk(L.res.cin) && chk(L.res.cout);
+  if (!ok) { set_error("a GroupNorm channel count is not divisible by norm_groups=%d", d.norm_groups); return SR3_E_BADARG; }
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activation plan (first-fit free list, byte offsets; sizes scale with batch)
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+  struct Blk { size_t off, size; };
+  std::vector<Blk> free_list;
+  size_t top = 0, high = 0;
+  size_t alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+      if (free_list[i].size >= bytes) {
+        const size_t off = free_list[i].off;
+        free_list[i].off += bytes;
+        free_list[i].size -= bytes;
+        if (free_list[i].size == 0) free_list.erase(free_list.begin() + i);
+        return off;
+      }
+    }
+    const size_t off = top;
+    top += bytes;
+    if (top > high) high = top;
+    return off;
+  }
+  void release(size_t off, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    free_list.push_back({off, bytes});
+    std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < free_list.size();) {
+      if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+        free_list[i].size += free_list[i + 1].size;
+        free_list.erase(free_list.begin() + i + 1);
+      } else {
+        ++i;
+      }
+    }
+    if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+      top = free_list.back().off;
+      free_list.pop_back();
+    }
+  }
+};
+
+struct Builder {
+  sr3_plan* P;
+  int B;
+  Arena act;
+  std::vector<Tensor> T;          // tensor table; handles are indices (shared state, no copies)
+  size_t stats_cursor = 0;
+  size_t max_scratch = 0;
+  int max_cin = 0;
+  double flops = 0;
+  std::vector<Op>& ops;
+  Builder(sr3_plan* p, int b) : P(p), B(b), ops(p->ops) {}
+
+  int make(int C, int H, int W) {
+    Tensor t;
+    t.C = C; t.H = H; t.W = W;
+    t.bytes = (size_t)B * H * W * C * sizeof(float);
+    t.off = act.alloc(t.bytes);
+    t.stat_off = stats_cursor;
+    stats_cursor += (size_t)B * C * 2 * sizeof(double);
+    t.valid = true;
+    T.push_back(t);
+    return (int)T.size() - 1;
+  }
+  void drop(int h) {
+    if (h < 0 || !T[h].valid) return;
+    if (!P->keep_all) act.release(T[h].off, T[h].bytes);
+    T[h].valid = false;
+  }
+  void ensure_stats(int h) {
+    Tensor& t = T[h];
+    if (t.stats_done) return;
+    Op o; o.kind = OP_STATS;
+    o.a = t.off; o.b = t.stat_off; o.i0 = t.H * t.W; o.i1 = t.C;
+    ops.push_back(o);
+    t.stats_done = true;
+  }
+  void fold(int x0, int x1, size_t gamma, size_t beta) {
+    ensure_stats(x0);
+    if (x1 >= 0) ensure_stats(x1);
+    Op o; o.kind = OP_FOLD;
+    o.a = T[x0].stat_off; o.i0 = T[x0].C;
+    o.has_st1 = x1 >= 0;
+    if (x1 >= 0) { o.b = T[x1].stat_off; o.i1 = T[x1].C; }
+    o.i2 = T[x0].H * T[x0].W;
+    o.p0 = gamma; o.p1 = beta;
+    ops.push_back(o);
+    max_cin = std::max(max_cin, T[x0].C + (x1 >= 0 ? T[x1].C : 0));
+  }
+  // generic conv over the virtual concat (x0|x1); residual is the concat view (r0|r1)
+  int conv(int x0, int x1, int Cout, int ksize, int stride, int ups, int act_mode, size_t w, bool has_bias,
+           size_t bias, int film_row, int r0, int r1, bool want_stats) {
+    const int C0 = T[x0].C, C1 = x1 >= 0 ? T[x1].C : 0;
+    const int Hi = T[x0].H << ups, Wi = T[x0].W << ups;
+    const int pad = ksize / 2;
+    const int Ho = (Hi + 2 * pad - ksize) / stride + 1, Wo = (Wi + 2 * pad - ksize) / stride + 1;
+    const int out = make(Cout, Ho, Wo);
+    Op o; o.kind = OP_CONV;
+    ConvParams& c = o.cp;
+    memset(&c, 0, sizeof(c));
+    c.C0 = C0; c.C1 = C1;
+    c.B = B; c.Hs = T[x0].H; c.Ws = T[x0].W; c.ups = ups; c.stride = stride; c.ksize = ksize;
+    c.Ho = Ho; c.Wo = Wo; c.Cout = Cout; c.act = act_mode;
+    c.film_stride = P->F;
+    c.RC0 = r0 >= 0 ? T[r0].C : 0; c.RC1 = r1 >= 0 ? T[r1].C : 0;
+    c.ksplit = 1;
+    o.a = T[x0].off; o.has_src1 = x1 >= 0; if (x1 >= 0) o.b = T[x1].off;
+    o.p0 = w; o.has_bias = has_bias; o.p1 = bias;
+    o.has_film = film_row >= 0; o.i0 = film_row;
+    o.has_res = r0 >= 0; if (r0 >= 0) o.c = T[r0].off;
+    o.has_res1 = r1 >= 0; if (r1 >= 0) o.d = T[r1].off;
+    o.e = T[out].off;
+    o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
+    conv_pick(c, o.tile_cfg, o.ksplit);
+    if (o.ksplit > 1) max_scratch = std::max(max_scratch, (size_t)o.ksplit * B * Ho * Wo * Cout * sizeof(float));
+    if (want_stats && P->fuse_stats && ((Ho * Wo) & 7) == 0) {
+      o.has_ostat = true; o.f = T[out].stat_off;
+      T[out].stats_done = true;
+    }
+    ops.push_back(o);
+    flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(C0 + C1) * ksize * ksize;
+    return out;
+  }
+  int res_block(int x0, int x1, const ResLayer& R) {
+    fold(x0, x1, R.gn1_w, R.gn1_b);
+    const int h1 = conv(x0, x1, R.cout, 3, 1, 0, 2, R.c1_w, true, R.c1_b, R.film_off, -1, -1, true);
+    fold(h1, -1, R.gn2_w, R.gn2_b);
+    int out;
+    if (R.has_rc) {
+      const int r = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, r, -1, true);
+      drop(r);
+    } else {
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, x0, x1, true);
+    }
+    drop(h1);
+    if (R.attn) {
+      fold(out, -1, R.an_w, R.an_b);
+      const int qkv = conv(out, -1, 3 * R.cout, 1, 1, 0, 1, R.qkv_w, false, 0, -1, -1, -1, false);
+      const int o = make(R.cout, T[out].H, T[out].W);
+      Op a; a.kind = OP_ATTN;
+      a.a = T[qkv].off; a.b = T[o].off; a.i0 = T[out].H * T[out].W; a.i1 = R.cout;
+      ops.push_back(a);
+      flops += 4.0 * B * (double)a.i0 * (double)a.i0 * R.cout;
+      drop(qkv);
+      const int out2 = conv(o, -1, R.cout, 1, 1, 0, 0, R.ao_w, true, R.ao_b, -1, out, -1, true);
+      drop(o);
+      drop(out);
+      out = out2;
+    }
+    return out;
+  }
+};
+
+static int build_forward(sr3_plan* P, int B, int cond_channels) {
+  if (P->built_batch == B && P->built_cond == cond_channels) return SR3_OK;
+  const sr3_unet_desc& d = P->d;
+  if (B <= 0) { set_error("batch must be > 0"); return SR3_E_BADARG; }
+  if (cond_channels < 0 || cond_channels >= d.in_channel) { set_error("cond_channels %d out of range (in_channel %d)", cond_channels, d.in_channel); return SR3_E_BADARG; }
+  P->ops.clear();
+  P->taps.clear();
+  Builder bld(P, B);
+  std::vector<Op>& ops = P->ops;
+  const int S = d.image_size, inner = d.inner_channel;
+
+  { Op o; o.kind = OP_MEMSET; ops.push_back(o); }
+  { Op o; o.kind = OP_EMBED; ops.push_back(o); }
+  bld.flops += 2.0 * B * (2.0 * 4 * inner * inner + (double)P->F * inner);
+
+  auto tap = [&](const std::string& name, int h) { P->taps.push_back({name, bld.T[h].off, bld.T[h].C, bld.T[h].H, bld.T[h].W}); };
+  std::vector<int> feats;
+  int cur = -1;
+  for (auto& L : P->downs) {
+    if (L.kind == 0) {
+      cur = bld.make(L.cout, S, S);
+      Op o; o.kind = OP_CONV_IN;
+      o.e = bld.T[cur].off; o.p0 = L.w; o.p1 = L.b;
+      o.i0 = d.in_channel - cond_channels; o.i1 = cond_channels; o.i2 = L.cout; o.i3 = S;
+      ops.push_back(o);
+      bld.flops += 2.0 * B * S * S * (double)L.cout * L.cin * 9;
+    } else if (L.kind == 1) {
+      cur = bld.res_block(cur, -1, L.res);   // the input stays alive: it is a skip feature
+    } else {
+      cur = bld.conv(cur, -1, L.cout, 3, 2, 0, 0, L.w, true, L.b, -1, -1, -1, true);
+    }
+    feats.push_back(cur);
+    tap(L.name, cur);
+  }
+  // `cur` is feats.back() here: skip features are released by the up block that consumes them
+  bool cur_is_skip = true;
+  for (auto& L : P->mid) {
+    const int nxt = bld.res_block(cur, -1, L.res);
+    if (!cur_is_skip) bld.drop(cur);
+    cur = nxt;
+    cur_is_skip = false;
+    tap(L.name, cur);
+  }
+  for (auto& L : P->ups) {
+    int nxt;
+    if (L.kind == 1) {
+      const int skip = feats.back();
+      feats.pop_back();
+      nxt = bld.res_block(cur, skip, L.res);
+      bld.drop(cur);
+      bld.drop(skip);
+    } else {
+      nxt = bld.conv(cur, -1, L.cout, 3, 1, 1, 0, L.w, true, L.b, -1, -1, -1, true);
+      bld.drop(cur);
+    }
+    cur = nxt;
+    tap(L.name, cur);
+  }
+  bld.fold(cur, -1, P->fin_gn_w, P->fin_gn_b);
+  {
+    Op o; o.kind = OP_CONV_OUT;
+    o.a = bld.T[cur].off; o.p0 = P->fin_w; o.p1 = P->fin_b; o.i0 = bld.T[cur].C; o.i1 = P->out_ch; o.i2 = S;
+    ops.push_back(o);
+    bld.flops += 2.0 * B * S * S * (double)P->out_ch * bld.T[cur].C * 9;
+  }
+  // ---- fixed regions after the activation arena (high-water mark) ----
+  size_t off = (bld.act.high + 255) & ~(size_t)255;
+  P->stats_off = off; P->stats_bytes = bld.stats_cursor; off += (bld.stats_cursor + 255) & ~(size_t)255;
+  P->ss_off = off; off += ((size_t)B * std::max(bld.max_cin, 4) * 2 * sizeof(float) + 255) & ~(size_t)255;
+  P->temb_off = off; off += ((size_t)B * inner * sizeof(float) + 255) & ~(size_t)255;
+  P->film_off = off; off += ((size_t)B * P->F * sizeof(float) + 255) & ~(size_t)255;
+  P->scratch_off = off; P->scratch_bytes = bld.max_scratch; off += (bld.max_scratch + 255) & ~(size_t)255;
+  P->ws_bytes = off;
+  P->flops = bld.flops;
+  P->built_batch = B;
+  P->built_cond = cond_channels;
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward driver
+// ---------------------------------------------------------------------------------------------
+static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_channels, const float* level,
+                       const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
+                       const float* params, char* ws, float* eps_out, int B, hipStream_t st) {
+  const sr3_unet_desc& d = P->d;
+  float* ss = reinterpret_cast<float*>(ws + P->ss_off);
+  float* film = reinterpret_cast<float*>(ws + P->film_off);
+  int last_hw = 0;
+  for (const Op& o : P->ops) {
+    int rc = SR3_OK;
+    switch (o.kind) {
+      case OP_MEMSET:
+        if (P->stats_bytes) SR3_HIP(hipMemsetAsync(ws + P->stats_off, 0, P->stats_bytes, st));
+        break;
+      case OP_EMBED: {
+        EmbedParams e;
+        memset(&e, 0, sizeof(e));
+        e.variant = d.variant; e.B = B; e.inner = d.inner_channel;
+        e.level = level; e.tstep = tstep; e.level_table = level_table; e.step_dev = step_dev; e.freq = freq;
+        e.w1 = params + P->emb_w1; e.b1 = params + P->emb_b1; e.w2 = params + P->emb_w2; e.b2 = params + P->emb_b2;
+        e.wf = params + P->film_w; e.bf = params + P->film_b; e.F = P->F;
+        e.temb = reinterpret_cast<float*>(ws + P->temb_off); e.film = film;
+        rc = embed_forward(e, st);
+        break;
+      }
+      case OP_CONV_IN: {
+        // virtual concat order is [cond | x] (diffusion.py:157); unconditional: x only
+        const float* a = cond_channels > 0 ? cond : x;
+        const int Ca = cond_channels > 0 ? cond_channels : o.i0;
+        const float* b = cond_channels > 0 ? x : nullptr;
+        const int Cb = cond_channels > 0 ? o.i0 : 0;
+        rc = conv_in_nchw(a, Ca, b, Cb, B, o.i3, o.i3, params + o.p0, params + o.p1, o.i2,
+                          reinterpret_cast<float*>(ws + o.e), nullptr, st);
+        break;
+      }
+      case OP_STATS:
+        rc = chan_stats(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1,
+                        reinterpret_cast<double*>(ws + P->stats_off + o.b), st);
+        break;
+      case OP_FOLD:
+        rc = gn_finalize(reinterpret_cast<const double*>(ws + P->stats_off + o.a), o.i0,
+                         o.has_st1 ? reinterpret_cast<const double*>(ws + P->stats_off + o.b) : nullptr,
+                         o.has_st1 ? o.i1 : 0, B, o.i2, d.norm_groups, params + o.p0, params + o.p1, 1e-5f, ss, st);
+        last_hw = o.i2;
+        break;
+      case OP_CONV: {
+        ConvParams c = o.cp;
+        c.src0 = reinterpret_cast<const float*>(ws + o.a);
+        c.src1 = o.has_src1 ? reinterpret_cast<const float*>(ws + o.b) : nullptr;
+        c.w = params + o.p0;
+        c.bias = o.has_bias ? params + o.p1 : nullptr;
+        c.ss = c.act ? ss : nullptr;
+        c.film = o.has_film ? film + o.i0 : nullptr;
+        c.res0 = o.has_res ? reinterpret_cast<const float*>(ws + o.c) : nullptr;
+        c.res1 = o.has_res1 ? reinterpret_cast<const float*>(ws + o.d) : nullptr;
+        c.out = reinterpret_cast<float*>(ws + o.e);
+        c.ostat = o.has_ostat ? reinterpret_cast<double*>(ws + P->stats_off + o.f) : nullptr;
+        rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + P->scratch_off), P->scratch_bytes, st);
+        break;
+      }
+      case OP_ATTN:
+        rc = attention_forward(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1,
+                               reinterpret_cast<float*>(ws + o.b), st);
+        break;
+      case OP_CONV_OUT:
+        rc = conv_out_nchw(reinterpret_cast<const float*>(ws + o.a), ss, B, o.i2, o.i2, o.i0, params + o.p0,
+                           params + o.p1, o.i1, eps_out, st);
+        break;
+    }
+    if (rc) return rc;
+  }
+  (void)last_hw;
+  return SR3_OK;
+}
+
+}  // namespace sr3
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int sr3_version(void) { return SR3_ABI_VERSION; }
+const char* sr3_last_error(void) { return sr3::last_error(); }
+
+int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out) {
+  if (!desc || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  sr3_plan* P = new (std::nothrow) sr3_plan();
+  if (!P) { set_error("out of host memory"); return SR3_E_NOMEM; }
+  P->d = *desc;
+  const int rc = build_structure(P);
+  if (rc) { delete P; *out = nullptr; return rc; }
+  *out = P;
+  return SR3_OK;
+}
+void sr3_plan_destroy(sr3_plan* plan) { delete plan; }
+int sr3_plan_num_params(const sr3_plan* plan) { return plan ? (int)plan->params.size() : 0; }
+int sr3_plan_param_info(const sr3_plan* plan, int index, sr3_param_info* out) {
+  if (!plan || !out || index < 0 || index >= (int)plan->params.size()) { set_error("bad param index"); return SR3_E_BADARG; }
+  *out = plan->params[index];
+  return SR3_OK;
+}
+size_t sr3_plan_param_floats(const sr3_plan* plan) { return plan ? plan->param_floats : 0; }
+int sr3_plan_num_ops(sr3_plan* plan, int batch) {
+  if (!plan) return 0;
+  const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
+  if (build_forward(plan, batch, cond)) return -1;
+  return (int)plan->ops.size();
+}
+double sr3_plan_forward_flops(sr3_plan* plan, int batch) {
+  if (!plan) return 0;
+  const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
+  if (build_forward(plan, batch, cond)) return -1;
+  return plan->flops;
+}
+int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
+  if (!plan || !key) return SR3_E_BADARG;
+  int* slot = nullptr;
+  if (!strcmp(key, "fuse_stats")) slot = &plan->fuse_stats;
+  else if (!strcmp(key, "tile_cfg")) slot = &plan->tile_cfg;
+  else if (!strcmp(key, "ksplit")) slot = &plan->ksplit;
+  else if (!strcmp(key, "keep_all")) slot = &plan->keep_all;
+  if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
+  const int prev = *slot;
+  *slot = value;
+  plan->built_batch = -1;
+  return prev;
+}
+int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }
+int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_t* offset, int* C, int* H, int* W) {
+  if (!plan || index < 0 || index >= (int)plan->taps.size()) { set_error("bad tap index"); return SR3_E_BADARG; }
+  const Tap& t = plan->taps[index];
+  if (name && name_len > 0) snprintf(name, name_len, "%s", t.name.c_str());
+  if (offset) *offset = t.off;
+  if (C) *C = t.C;
+  if (H) *H = t.H;
+  if (W) *W = t.W;
+  return SR3_OK;
+}
+
+size_t sr3_workspace_bytes(sr3_plan* plan, int batch) {
+  if (!plan) return 0;
+  const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
+  if (build_forward(plan, batch, cond)) return 0;
+  return plan->ws_bytes;
+}
+
+int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
+                     const float* noise_level, const int64_t* timestep, const float* freq, const float* level_table,
+                     const int* step_dev, const float* params, void* workspace, size_t workspace_bytes,
+                     float* eps_out_nchw, int batch, void* stream) {
+  if (!plan || !x_nchw || !params || !workspace || !eps_out_nchw || !freq) { set_error("null argument"); return SR3_E_BADARG; }
+  if (!cond_nchw) cond_channels = 0;
+  const int rc = build_forward(plan, batch, cond_channels);
+  if (rc) return rc;
+  if (workspace_bytes < plan->ws_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, plan->ws_bytes); return SR3_E_NOMEM; }
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)x_nchw & 15) || ((uintptr_t)eps_out_nchw & 15)) {
+    set_error("misaligned pointer (workspace 256 B, tensors 16 B)");
+    return SR3_E_ALIGN;
+  }
+  if (plan->d.variant == SR3_VARIANT_SR3 && !noise_level && !step_dev) { set_error("SR3 variant needs noise_level or step_dev"); return SR3_E_BADARG; }
+  if (plan->d.variant == SR3_VARIANT_DDPM && !timestep && !step_dev) { set_error("DDPM variant needs timestep or step_dev"); return SR3_E_BADARG; }
+  return run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, level_table, step_dev, params,
+                     static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream));
+}
+
+int sr3_p_sample_step(float* x, const float* eps, const float* z, const float* ta, const float* tb, const float* tc1,
+                      const float* tc2, const float* tsig, const int* step_dev, const int64_t* t_per_sample,
+                      int step_host, int batch, int elems_per_image, void* stream) {
+  if (!x || !eps || !ta || !tb || !tc1 || !tc2 || !tsig) { set_error("null argument"); return SR3_E_BADARG; }
+  StepTables t{ta, tb, tc1, tc2, tsig};
+  return p_sample_update(x, eps, z, t, step_dev, t_per_sample, step_host, batch, elems_per_image,
+                         static_cast<hipStream_t>(stream));
+}
+int sr3_step_decrement(int* step_dev, void* stream) { return step_decrement(step_dev, static_cast<hipStream_t>(stream)); }
+int sr3_q_sample(const float* x0, const float* z, const float* ca, const float* cb, int batch, int elems_per_image,
+                 float* out, void* stream) {
+  if (!x0 || !z || !ca || !cb || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  return q_sample(x0, z, ca, cb, batch, elems_per_image, out, static_cast<hipStream_t>(stream));
+}
+
+int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups, int stride,
+                 int ksize, int Cout, const float* w, const float* bias, const float* ss, int act, const float* film,
+                 int film_stride, const float* res0, int RC0, const float* res1, int RC1, float* out, double* out_stats,
+                 int tile_cfg, int ksplit, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!src0 || !w || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  ConvParams c;
+  memset(&c, 0, sizeof(c));
+  c.src0 = src0; c.src1 = src1; c.C0 = C0; c.C1 = src1 ? C1 : 0;
+  c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = stride; c.ksize = ksize;
+  const int pad = ksize / 2;
+  c.Ho = ((Hs << ups) + 2 * pad - ksize) / stride + 1;
+  c.Wo = ((Ws << ups) + 2 * pad - ksize) / stride + 1;
+  c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
+  c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
+  c.out = out; c.ostat = out_stats; c.ksplit = 1;
+  if (out_stats && ((c.Ho * c.Wo) & 7)) { set_error("fused stats need Ho*Wo %% 8 == 0"); return SR3_E_UNSUPPORTED; }
+  return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
+}
+size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit) {
+  ConvParams c;
+  memset(&c, 0, sizeof(c));
+  c.B = B; c.Ho = Ho; c.Wo = Wo; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
+  return conv_splitk_bytes(c, tile_cfg, ksplit);
+}
+int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, void* stream) {
+  if (!x || !stat) { set_error("null argument"); return SR3_E_BADARG; }
+  return chan_stats(x, B, HW, C, stat, static_cast<hipStream_t>(stream));
+}
+int sr3_groupnorm_fold_f32(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+                           const float* gamma, const float* beta, float eps, float* ss, void* stream) {
+  if (!stat0 || !gamma || !beta || !ss) { set_error("null argument"); return SR3_E_BADARG; }
+  return gn_finalize(stat0, C0, stat1, stat1 ? C1 : 0, B, HW, groups, gamma, beta, eps, ss, static_cast<hipStream_t>(stream));
+}
+int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream) {
+  if (!qkv || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  return attention_forward(qkv, B, N, C, out, static_cast<hipStream_t>(stream));
+}
+int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep, const float* freq,
+                       const float* w1, const float* b1, const float* w2, const float* b2, const float* wf,
+                       const float* bf, int F, float* temb_scratch, float* film_out, void* stream) {
+  EmbedParams e;
+  memset(&e, 0, sizeof(e));
+  e.variant = variant; e.B = B; e.inner = inner; e.level = level; e.tstep = timestep; e.freq = freq;
+  e.w1 = w1; e.b1 = b1; e.w2 = w2; e.b2 = b2; e.wf = wf; e.bf = bf; e.F = F; e.temb = temb_scratch; e.film = film_out;
+  return embed_forward(e, static_cast<hipStream_t>(stream));
+}
+int sr3_conv_in_f32(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
+                    const float* bias, int Cout, float* out, void* stream) {
+  return conv_in_nchw(a, Ca, b, b ? Cb : 0, B, H, W, w, bias, Cout, out, nullptr, static_cast<hipStream_t>(stream));
+}
+int sr3_conv_out_f32(const float* x, const float* ss, int B, int H, int W, int C, const float* w, const float* bias,
+                     int Cout, float* out, void* stream) {
+  return conv_out_nchw(x, ss, B, H, W, C, w, bias, Cout, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

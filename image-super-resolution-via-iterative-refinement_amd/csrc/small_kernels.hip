@@ -1,0 +1,418 @@
+// HBM-bound helpers of the SR3 / DDPM hot path (gfx950): GroupNorm statistics and folding,
+// the 6->C input conv (NCHW -> NHWC), the C->3 output Block (NHWC -> NCHW), the noise-level /
+// timestep embedding with every FiLM projection, and the fused reverse-step / q_sample updates.
+#include "sr3_common.h"
+
+namespace sr3 {
+
+__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+
+// ---------------------------------------------------------------------------------------------
+// per-(image, channel) sum / sum-of-squares in double.  x: NHWC [B][HW][C].
+// Feeds nn.GroupNorm (model/sr3_modules/unet.py:84,119): keeping *channel* sums lets one pass
+// serve any grouping, including groups that straddle a skip-concat seam (unet.py:255).
+// grid (slices, cblocks, B); LQ lanes across channel quads, 256/LQ lanes across pixels.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int HW, int C, int LQ,
+                                                     int pix_per_block, double* __restrict__ stat) {
+  __shared__ double red[256 * 8];
+  const int tid = threadIdx.x;
+  const int nq = C >> 2;
+  const int ql = tid % LQ, pl = tid / LQ, PP = 256 / LQ;
+  const int q = blockIdx.y * LQ + ql;
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(HW, p0 + pix_per_block);
+  double s[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (q < nq) {
+    const float* base = x + (size_t)b * HW * C + q * 4;
+    for (int p = p0 + pl; p < p1; p += PP) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const double d = (double)v[e]; s[e] += d; s2[e] += d * d; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = s[e]; red[tid * 8 + 4 + e] = s2[e]; }
+  __syncthreads();
+  if (pl == 0 && q < nq) {
+    for (int k = 1; k < PP; ++k) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] += red[(k * LQ + ql) * 8 + e]; s2[e] += red[(k * LQ + ql) * 8 + 4 + e]; }
+    }
+    double* o = stat + ((size_t)b * C + q * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { atomicAdd(o + 2 * e, s[e]); atomicAdd(o + 2 * e + 1, s2[e]); }
+  }
+}
+
+int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st) {
+  if (C & 3) { set_error("chan_stats: C %% 4 != 0 (%d)", C); return SR3_E_UNSUPPORTED; }
+  const int nq = C >> 2;
+  int LQ = 1;
+  while (LQ < nq && LQ < 64) LQ <<= 1;
+  const int cblocks = (nq + LQ - 1) / LQ;
+  const int PP = 256 / LQ;
+  long base_blocks = (long)cblocks * B;
+  long want = 2048 / (base_blocks > 0 ? base_blocks : 1);
+  if (want < 1) want = 1;
+  long max_slices = (HW + PP - 1) / PP;
+  if (want > max_slices) want = max_slices;
+  int ppb = (int)((HW + want - 1) / want);
+  ppb = ((ppb + PP - 1) / PP) * PP;
+  const int slices = (HW + ppb - 1) / ppb;
+  hipLaunchKernelGGL(k_chan_stats, dim3(slices, cblocks, B), dim3(256), 0, st, x, HW, C, LQ, ppb, stat);
+  SR3_LAUNCH_CHECK("k_chan_stats");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm fold: scale = rstd * gamma, shift = beta - mean * scale per (image, channel) of the
+// virtual concat [src0 | src1].  Biased variance, eps inside the sqrt (torch GroupNorm).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ st0, int C0,
+                                                      const double* __restrict__ st1, int C1, int B, int HW,
+                                                      int groups, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      float* __restrict__ ss) {
+  const int C = C0 + C1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  const int cpg = C / groups;
+  const int g0 = (c / cpg) * cpg;
+  double s = 0.0, s2 = 0.0;
+  for (int k = g0; k < g0 + cpg; ++k) {
+    const double* q = (k < C0) ? st0 + ((size_t)b * C0 + k) * 2 : st1 + ((size_t)b * C1 + (k - C0)) * 2;
+    s += q[0]; s2 += q[1];
+  }
+  const double cnt = (double)HW * cpg;
+  const double mean = s / cnt;
+  double var = s2 / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = rstd * gamma[c];
+  ss[(size_t)idx * 2] = sc;
+  ss[(size_t)idx * 2 + 1] = beta[c] - (float)mean * sc;
+}
+
+int gn_finalize(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st) {
+  const int C = C0 + C1;
+  if (groups <= 0 || C % groups) { set_error("gn_finalize: C=%d not divisible by groups=%d", C, groups); return SR3_E_BADARG; }
+  const int n = B * C;
+  hipLaunchKernelGGL(k_gn_finalize, dim3((n + 255) / 256), dim3(256), 0, st, stat0, C0, stat1, C1, B, HW, groups,
+                     gamma, beta, eps, ss);
+  SR3_LAUNCH_CHECK("k_gn_finalize");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input conv (unet.py:193-194): 3x3 pad 1 over the virtual concat of two NCHW tensors
+// (`torch.cat([condition_x, x], dim=1)`, diffusion.py:157) -> NHWC.  K = 9*(Ca+Cb) is tiny (54),
+// so this is a direct fp32 FMA kernel bound by the NHWC write: lanes = 64 consecutive pixels
+// (coalesced NCHW reads), the 4 waves of a block each own 16 of every 64 output channels and read
+// their weights as LDS broadcasts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_conv_in_nchw(const float* __restrict__ a, int Ca,
+                                                       const float* __restrict__ bsrc, int Cb, int B, int H,
+                                                       int W, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int Cout,
+                                                       float* __restrict__ out) {
+  extern __shared__ f32x4 smem_v[];
+  float* wl = reinterpret_cast<float*>(smem_v);          // [K][CoutP]  (k-major, CoutP = Cout rounded to 64)
+  const int Cin = Ca + Cb;
+  const int K = 9 * Cin;
+  const int CoutP = (Cout + 63) & ~63;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * CoutP; i += 256) {
+    const int k = i / CoutP, n = i - k * CoutP;
+    const int tap = k / Cin, c = k - tap * Cin;
+    wl[i] = (n < Cout) ? w[((size_t)n * 9 + tap) * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  const int HWp = H * W;
+  const long M = (long)B * HWp;
+  const long m = (long)blockIdx.x * 64 + (tid & 63);
+  const int cog = tid >> 6;                                // wave index = output-channel group
+  if (m >= M) return;
+  const int b = (int)(m / HWp);
+  const int rem = (int)(m - (long)b * HWp);
+  const int oh = rem / W, ow = rem - oh * W;
+  for (int cobase = 0; cobase < Cout; cobase += 64) {
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ih = oh + tap / 3 - 1, iw = ow + tap % 3 - 1;
+      const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      for (int c = 0; c < Cin; ++c) {
+        float v = 0.f;
+        if (ok) {
+          v = (c < Ca) ? a[((size_t)b * Ca + c) * HWp + (size_t)ih * W + iw]
+                       : bsrc[((size_t)b * Cb + (c - Ca)) * HWp + (size_t)ih * W + iw];
+        }
+        const float* wr = wl + (size_t)(tap * Cin + c) * CoutP + cobase + cog * 16;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          const f32x4 ww = *reinterpret_cast<const f32x4*>(wr + e4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e4 * 4 + e] = fmaf(v, ww[e], acc[e4 * 4 + e]);
+        }
+      }
+    }
+    const int co0 = cobase + cog * 16;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const int co = co0 + e4 * 4;
+      if (co < Cout) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[e4 * 4 + e] + (bias ? bias[co + e] : 0.f);
+        *reinterpret_cast<f32x4*>(out + (size_t)m * Cout + co) = o;
+      }
+    }
+  }
+}
+
+int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
+                 const float* bias, int Cout, float* out, double* ostat, hipStream_t st) {
+  (void)ostat;
+  if (Cout & 3) { set_error("conv_in: Cout %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const int CoutP = (Cout + 63) & ~63;
+  const size_t smem = (size_t)9 * (Ca + Cb) * CoutP * sizeof(float);
+  if (smem > 64 * 1024) { set_error("conv_in: weights do not fit LDS (%zu B)", smem); return SR3_E_UNSUPPORTED; }
+  const long M = (long)B * H * W;
+  hipLaunchKernelGGL(k_conv_in_nchw, dim3((unsigned)((M + 63) / 64)), dim3(256), smem, st, a, Ca, b, Cb, B, H, W, w,
+                     bias, Cout, out);
+  SR3_LAUNCH_CHECK("k_conv_in_nchw");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output Block (unet.py:233,259): GroupNorm -> Swish -> conv3x3 C -> Cout (3).  N = 3 is no GEMM;
+// the kernel is bound by one read of the NHWC input.  A block owns an 8x32 pixel tile; per 16-
+// channel chunk it stages the (10x34) halo tile *after* GN+SiLU in LDS (each element transformed
+// once, zero padding applied after the activation as the reference does), then every thread
+// accumulates its pixel's Cout outputs from LDS.  Writes NCHW (the public layout of eps).
+// ---------------------------------------------------------------------------------------------
+constexpr int OT_H = 8, OT_W = 32, OT_CK = 16, OT_LD = 20;
+__global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__ x, const float* __restrict__ ss,
+                                                        int B, int H, int W, int C, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int Cout,
+                                                        float* __restrict__ out) {
+  __shared__ f32x4 tile_v[(OT_H + 2) * (OT_W + 2) * OT_LD / 4];
+  __shared__ f32x4 wl_v[4 * 9 * OT_CK / 4];
+  float* tile = reinterpret_cast<float*>(tile_v);
+  float* wl = reinterpret_cast<float*>(wl_v);              // [co][tap][16]
+  const int tid = threadIdx.x;
+  const int tx = tid & 31, ty = tid >> 5;
+  const int tiles_w = (W + OT_W - 1) / OT_W, tiles_h = (H + OT_H - 1) / OT_H;
+  int bid = blockIdx.x;
+  const int b = bid / (tiles_w * tiles_h);
+  bid -= b * tiles_w * tiles_h;
+  const int th = bid / tiles_w, tw = bid - th * tiles_w;
+  const int h0 = th * OT_H, w0 = tw * OT_W;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NPIX = (OT_H + 2) * (OT_W + 2);
+  for (int c0 = 0; c0 < C; c0 += OT_CK) {
+    __syncthreads();
+    for (int i = tid; i < NPIX * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int py = pix / (OT_W + 2), px = pix - py * (OT_W + 2);
+      const int ih = h0 + py - 1, iw = w0 + px - 1;
+      const int c = c0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < C && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + ih) * W + iw) * C + c);
+        const float* s = ss + ((size_t)b * C + c) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_s(fmaf(v[e], s[2 * e], s[2 * e + 1]));
+      }
+      *reinterpret_cast<f32x4*>(tile + pix * OT_LD + q * 4) = v;
+    }
+    for (int i = tid; i < 4 * 9 * OT_CK; i += 256) {
+      const int co = i / (9 * OT_CK), r = i - co * 9 * OT_CK;
+      const int tap = r / OT_CK, c = c0 + (r - tap * OT_CK);
+      wl[i] = (co < Cout && c < C) ? w[((size_t)co * 9 + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* tp = tile + ((ty + tap / 3) * (OT_W + 2) + tx + tap % 3) * OT_LD;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tp + q * 4);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+          const f32x4 ww = *reinterpret_cast<const f32x4*>(wl + (co * 9 + tap) * OT_CK + q * 4);
+          acc[co] = fmaf(v[0], ww[0], acc[co]);
+          acc[co] = fmaf(v[1], ww[1], acc[co]);
+          acc[co] = fmaf(v[2], ww[2], acc[co]);
+          acc[co] = fmaf(v[3], ww[3], acc[co]);
+        }
+      }
+    }
+  }
+  const int oh = h0 + ty, ow = w0 + tx;
+  if (oh < H && ow < W) {
+    for (int co = 0; co < Cout; ++co)
+      out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + (bias ? bias[co] : 0.f);
+  }
+}
+
+int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, const float* w, const float* bias,
+                  int Cout, float* out_nchw, hipStream_t st) {
+  if (Cout > 4 || Cout < 1) { set_error("conv_out: Cout %d > 4 unsupported", Cout); return SR3_E_UNSUPPORTED; }
+  if (C & 3) { set_error("conv_out: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const int tiles = ((W + OT_W - 1) / OT_W) * ((H + OT_H - 1) / OT_H) * B;
+  hipLaunchKernelGGL(k_conv_out_nchw, dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw);
+  SR3_LAUNCH_CHECK("k_conv_out_nchw");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding: PositionalEncoding / TimeEmbedding -> Linear -> Swish -> Linear (unet.py:18-31,
+// 179-184; ddpm unet.py:19-34,165-170), then every per-block projection at once:
+// FeatureWiseAffine Linear(inner -> Cout) (sr3 unet.py:34-50) or Swish -> Linear (ddpm :81-84).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
+  extern __shared__ f32x4 smem_v[];
+  float* enc = reinterpret_cast<float*>(smem_v);           // [inner]
+  float* hid = enc + p.inner;                              // [4*inner]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int half = p.inner / 2;
+  float lv;
+  if (p.variant == 0) {
+    lv = p.step_dev ? p.level_table[p.step_dev[0] + 1] : p.level[b];
+  } else {
+    lv = p.step_dev ? (float)p.step_dev[0] : (float)p.tstep[b];
+  }
+  for (int k = tid; k < half; k += 256) {
+    const float arg = lv * p.freq[k];
+    enc[k] = sinf(arg);
+    enc[half + k] = cosf(arg);
+  }
+  __syncthreads();
+  const int hdim = 4 * p.inner;
+  for (int j = tid; j < hdim; j += 256) {
+    float s = p.b1[j];
+    const float* wr = p.w1 + (size_t)j * p.inner;
+    for (int k = 0; k < p.inner; ++k) s = fmaf(wr[k], enc[k], s);
+    hid[j] = silu_s(s);
+  }
+  __syncthreads();
+  for (int j = tid; j < p.inner; j += 256) {
+    float s = p.b2[j];
+    const float* wr = p.w2 + (size_t)j * hdim;
+    for (int k = 0; k < hdim; ++k) s = fmaf(wr[k], hid[k], s);
+    p.temb[(size_t)b * p.inner + j] = (p.variant == 1) ? silu_s(s) : s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_film(const EmbedParams p) {
+  extern __shared__ f32x4 smem_v[];
+  float* e = reinterpret_cast<float*>(smem_v);
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < p.inner; k += 256) e[k] = p.temb[(size_t)b * p.inner + k];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= p.F) return;
+  float s = p.bf[j];
+  const float* wr = p.wf + (size_t)j * p.inner;
+  for (int k = 0; k < p.inner; ++k) s = fmaf(wr[k], e[k], s);
+  p.film[(size_t)b * p.F + j] = s;
+}
+
+int embed_forward(const EmbedParams& p, hipStream_t st) {
+  if (p.inner & 1) { set_error("embed: inner must be even"); return SR3_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(k_embed, dim3(p.B), dim3(256), (size_t)5 * p.inner * sizeof(float), st, p);
+  SR3_LAUNCH_CHECK("k_embed");
+  if (p.F > 0) {
+    hipLaunchKernelGGL(k_film, dim3((p.F + 255) / 256, p.B), dim3(256), (size_t)p.inner * sizeof(float), st, p);
+    SR3_LAUNCH_CHECK("k_film");
+  }
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused reverse step (sr3 diffusion.py:141-149,162-174; ddpm :151-198):
+//   x0 = a_t x - b_t eps ; clamp[-1,1] ; mean = c1_t x0 + c2_t x ; x <- mean + sigma_t z
+// sigma_t = exp(0.5 logvar_t) with sigma_0 := 0 (the reference's `t > 0` branch / nonzero_mask).
+// Each product/sum is rounded separately (no contraction) so the update is bit-identical to the
+// reference's elementwise torch ops for the same eps.  t comes from a device counter (graph
+// replay), a per-sample int64 array (DDPM API) or the host.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_p_sample_update(float* __restrict__ x, const float* __restrict__ eps,
+                                                          const float* __restrict__ z, StepTables tb,
+                                                          const int* __restrict__ step_dev,
+                                                          const int64_t* __restrict__ tps, int step_host,
+                                                          int per_image, size_t total4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = i * 4;
+    const int b = (int)(e0 / per_image);
+    const int t = step_dev ? step_dev[0] : (tps ? (int)tps[b] : step_host);
+    const float a = tb.a[t], bb = tb.b[t], c1 = tb.c1[t], c2 = tb.c2[t], sg = tb.sigma[t];
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + e0);
+    const f32x4 ev = *reinterpret_cast<const f32x4*>(eps + e0);
+    f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+    if (z) zv = *reinterpret_cast<const f32x4*>(z + e0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x0 = __fsub_rn(__fmul_rn(a, xv[k]), __fmul_rn(bb, ev[k]));
+      x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv[k]));
+      xv[k] = __fadd_rn(mean, __fmul_rn(zv[k], sg));
+    }
+    *reinterpret_cast<f32x4*>(x + e0) = xv;
+  }
+}
+
+int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
+                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st) {
+  if (per_image & 3) { set_error("p_sample_update: per-image size %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const size_t total4 = (size_t)B * per_image / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_p_sample_update, dim3(blocks), dim3(256), 0, st, x, eps, z, tb, step_dev, t_per_sample,
+                     step_host, per_image, total4);
+  SR3_LAUNCH_CHECK("k_p_sample_update");
+  return SR3_OK;
+}
+
+__global__ void k_step_decrement(int* s) { if (threadIdx.x == 0 && blockIdx.x == 0) s[0] -= 1; }
+int step_decrement(int* step_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_step_decrement, dim3(1), dim3(64), 0, st, step_dev);
+  SR3_LAUNCH_CHECK("k_step_decrement");
+  return SR3_OK;
+}
+
+// q_sample: out = ca[b] * x0 + cb[b] * z   (sr3 diffusion.py:212-219, ddpm :259-267)
+__global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x0, const float* __restrict__ z,
+                                                   const float* __restrict__ ca, const float* __restrict__ cb,
+                                                   int per_image, size_t total4, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e0 = i * 4;
+    const int b = (int)(e0 / per_image);
+    const float a = ca[b], s = cb[b];
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x0 + e0);
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + e0);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(a, xv[k]), __fmul_rn(s, zv[k]));
+    *reinterpret_cast<f32x4*>(out + e0) = o;
+  }
+}
+
+int q_sample(const float* x0, const float* z, const float* ca, const float* cb, int B, int per_image, float* out,
+             hipStream_t st) {
+  if (per_image & 3) { set_error("q_sample: per-image size %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const size_t total4 = (size_t)B * per_image / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_q_sample, dim3(blocks), dim3(256), 0, st, x0, z, ca, cb, per_image, total4, out);
+  SR3_LAUNCH_CHECK("k_q_sample");
+  return SR3_OK;
+}
+
+}  // namespace sr3

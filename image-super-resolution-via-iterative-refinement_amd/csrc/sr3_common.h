@@ -1,0 +1,108 @@
+// Internal shared declarations for libsr3_mi355x (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/sr3_mi355x.h"
+
+namespace sr3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- error plumbing (thread-local message, int codes: 0 ok, >0 hipError_t, <0 engine) ----
+enum { SR3_OK = 0 };   // SR3_E_* come from the public header
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+#define SR3_HIP(call)                                   \
+  do {                                                  \
+    hipError_t _e = (call);                             \
+    if (_e != hipSuccess) return sr3::hip_fail(_e, #call); \
+  } while (0)
+#define SR3_LAUNCH_CHECK(name)                          \
+  do {                                                  \
+    hipError_t _e = hipGetLastError();                  \
+    if (_e != hipSuccess) return sr3::hip_fail(_e, name); \
+  } while (0)
+
+// ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
+// Activations are NHWC fp32.  The input is the *virtual* channel concat of up to two sources,
+// optionally nearest-upsampled x2 (gather in the address math), optionally strided.
+// Prologue (per input element, before zero padding): none | x*scale+shift | silu(x*scale+shift)
+// with (scale, shift) per (image, input channel) = GroupNorm folded with its affine.
+// Epilogue: + bias[n] + film[b][n] + residual[m][n] (residual is itself a two-source concat view).
+struct ConvParams {
+  const float* src0;
+  const float* src1;
+  int C0, C1;          // channels of src0 / src1 (C1 = 0 when no concat); both % 4 == 0
+  int B, Hs, Ws;       // source spatial dims
+  int ups;             // 1: nearest x2 upsample of the source before the conv
+  int stride;          // 1 | 2
+  int ksize;           // 1 | 3  (pad = ksize / 2)
+  int Ho, Wo;          // output spatial dims
+  int Cout;
+  const float* w;      // [Cout][ksize*ksize][Cin]   (OHWI)
+  const float* bias;   // [Cout] or null
+  const float* ss;     // [B][Cin][2] (scale, shift) or null
+  int act;             // 0 none, 1 affine, 2 affine + SiLU
+  const float* film;   // film[b * film_stride + n] or null
+  int film_stride;
+  const float* res0;   // residual, NHWC [B,Ho,Wo,RC0 (+RC1)] or null
+  const float* res1;
+  int RC0, RC1;
+  float* out;          // [B,Ho,Wo,Cout]
+  float* partial;      // split-K scratch [ksplit][M][Cout] (ksplit > 1)
+  int ksplit;
+  double* ostat;       // optional: per-(b, n) {sum, sumsq} accumulators of the OUTPUT (fused GN stats)
+};
+
+// tile_cfg: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 ; ksplit: 0 = auto
+int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_scratch,
+                 size_t splitk_scratch_bytes, hipStream_t st);
+// scratch bytes the auto heuristic may ask for (upper bound) for this problem
+size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
+void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
+
+// ---- small kernels ------------------------------------------------------------------------
+// per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]; stat must be zeroed.
+int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st);
+// GroupNorm fold: (chanstat of up to two concat sources) + gamma/beta -> ss[B][C0+C1][2]
+int gn_finalize(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st);
+// first conv of the UNet: NCHW inputs (virtual concat of a: Ca, b: Cb channels), 3x3 pad 1,
+// weights OHWI [Cout][9][Ca+Cb], output NHWC [B,H,W,Cout]
+int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
+                 const float* bias, int Cout, float* out, double* ostat, hipStream_t st);
+// final Block: silu(gn(x)) -> conv3x3 C->Cout(<=4), NHWC in, NCHW out
+int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, const float* w,
+                  const float* bias, int Cout, float* out_nchw, hipStream_t st);
+// noise-level / timestep embedding + MLP + all FiLM projections
+struct EmbedParams {
+  int variant;            // 0 sr3 (continuous level), 1 ddpm (integer t)
+  int B, inner;           // embedding dim = inner, hidden = 4*inner
+  const float* level;     // [B] (sr3) or null
+  const int64_t* tstep;   // [B] (ddpm) or null
+  const float* level_table;  // sr3: level = level_table[step_dev[0] + 1] when step_dev != null
+  const int* step_dev;    // device step counter (graph replay) or null
+  const float* freq;      // [inner/2] frequency table
+  const float* w1; const float* b1;   // [4*inner][inner], [4*inner]
+  const float* w2; const float* b2;   // [inner][4*inner], [inner]
+  const float* wf; const float* bf;   // concatenated FiLM projections [F][inner], [F]
+  int F;
+  float* temb;            // [B][inner] scratch
+  float* film;            // [B][F]
+};
+int embed_forward(const EmbedParams& p, hipStream_t st);
+// single-head attention over NHWC qkv [B][N][3C] -> out [B][N][C]
+int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st);
+// fused reverse-step update (NCHW, elementwise): coef = {a, b, c1, c2, sigma} tables of length T
+struct StepTables { const float* a; const float* b; const float* c1; const float* c2; const float* sigma; };
+int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
+                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st);
+int step_decrement(int* step_dev, hipStream_t st);
+// q_sample (sr3: per-sample gamma; ddpm: a[t], s[t]) -> x_noisy ; l1 loss sum
+int q_sample(const float* x0, const float* z, const float* ca, const float* cb, int B, int per_image,
+             float* out, hipStream_t st);
+
+}  // namespace sr3

@@ -1,0 +1,144 @@
+"""nn.Module faces of the engine: the objects `define_G` hands to the reference's callers.
+
+`EngineUNet` is what `GaussianDiffusion.denoise_fn` is in the reference
+(model/sr3_modules/unet.py:161-259, model/ddpm_modules/unet.py:147-243): same constructor
+arguments, same `forward(x, time)`, same state-dict keys and shapes -- but it owns one packed
+parameter arena and every FLOP runs in libsr3_mi355x.so.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import engine as E
+from . import lib as L
+
+
+def _is_norm(name):
+    return '.block.0.' in name or '.norm.' in name
+
+
+class EngineUNet(nn.Module):
+    variant = 'sr3'
+
+    def __init__(self, in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
+                 channel_mults=(1, 2, 4, 8, 8), attn_res=(8), res_blocks=3, dropout=0,
+                 with_noise_level_emb=True, image_size=128):
+        super().__init__()
+        if not with_noise_level_emb:
+            raise NotImplementedError('the engine always conditions on the noise level / timestep '
+                                      '(define_G never disables it: model/networks.py:91-101)')
+        self.plan = E.Plan(self.variant, in_channel, out_channel, inner_channel, norm_groups, channel_mults,
+                           attn_res, res_blocks, image_size)
+        self.dropout = float(dropout)
+        self.arena = nn.Parameter(torch.zeros(self.plan.param_floats, dtype=torch.float32), requires_grad=False)
+        self.register_buffer('freq', self.plan.default_freq(), persistent=False)
+        self._ws = E.Workspace()
+        self.reset_parameters()
+
+    # ---- initialisation: same distributions AND same RNG consumption order as the reference ----
+    def reset_parameters(self):
+        """PyTorch default init of Conv2d / Linear / GroupNorm, drawn in the reference's module
+        construction order so a given torch seed yields the reference's weights."""
+        fan_in = 1
+        for e in self.plan.table:
+            v = self.plan.view(self.arena.data, e)
+            name = e['name']
+            if _is_norm(name):
+                v.fill_(1.0 if name.endswith('weight') else 0.0)
+            elif len(e['shape']) >= 2:
+                t = torch.empty(e['shape'], dtype=torch.float32)
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+                fan_in = t[0].numel()
+                v.copy_(t)
+            else:
+                bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+                t = torch.empty(e['shape'], dtype=torch.float32)
+                nn.init.uniform_(t, -bound, bound)
+                v.copy_(t)
+
+    def init_orthogonal(self):
+        """weights_init_orthogonal (model/networks.py:42-55) in `net.apply` order."""
+        for e in self.plan.table:
+            name = e['name']
+            if _is_norm(name):
+                continue
+            v = self.plan.view(self.arena.data, e)
+            if len(e['shape']) >= 2:
+                t = torch.empty(e['shape'], dtype=torch.float32)
+                nn.init.orthogonal_(t, gain=1)
+                v.copy_(t.to(v.device))
+            else:
+                v.zero_()
+
+    # ---- parameter / state-dict surface --------------------------------------------------------
+    def named_parameters(self, prefix='', recurse=True, remove_duplicate=True):
+        for e in self.plan.table:
+            yield (prefix + ('.' if prefix else '') + e['name'], self.plan.view(self.arena.data, e))
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self.variant == 'ddpm':
+            destination[prefix + 'time_mlp.0.inv_freq'] = self.freq.detach().clone()
+        for e in self.plan.table:
+            destination[prefix + e['name']] = self.plan.view(self.arena.data, e).detach().clone().contiguous()
+
+    def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
+        # reference key order: buffers of a submodule come after its parameters; rebuild in table order
+        if destination is None:
+            destination = OrderedDict()
+        self._save_to_state_dict(destination, prefix, keep_vars)
+        return destination
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        known = set()
+        for e in self.plan.table:
+            key = prefix + e['name']
+            known.add(key)
+            if key not in state_dict:
+                missing_keys.append(key)
+                continue
+            src = state_dict[key]
+            if tuple(src.shape) != tuple(e['shape']):
+                error_msgs.append('size mismatch for %s: checkpoint %s vs model %s'
+                                  % (key, tuple(src.shape), tuple(e['shape'])))
+                continue
+            self.plan.view(self.arena.data, e).copy_(src.to(self.arena.device, torch.float32))
+        fkey = prefix + 'time_mlp.0.inv_freq'
+        if self.variant == 'ddpm':
+            known.add(fkey)
+            if fkey in state_dict:
+                self.freq.copy_(state_dict[fkey].to(self.freq.device, torch.float32))
+            else:
+                missing_keys.append(fkey)
+        if strict:
+            for k in state_dict.keys():
+                if k.startswith(prefix) and k not in known:
+                    unexpected_keys.append(k)
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, x, time, cond=None, level_table=None, step_dev=None, out=None):
+        """eps = UNet(x, time).  `x` may already contain the conditioning channels (reference call
+        convention `denoise_fn(torch.cat([cond, x], 1), level)`), or they can be passed separately as
+        `cond`, which the input conv reads as a virtual concat (nothing is materialised)."""
+        kw = {}
+        if step_dev is None:
+            if self.variant == 'sr3':
+                kw['noise_level'] = time
+            else:
+                kw['timestep'] = time
+        return E.unet_forward(self.plan, self.arena.data, self.freq, self._ws, x, cond=cond,
+                              level_table=level_table, step_dev=step_dev, out=out, **kw)
+
+    def extra_repr(self):
+        d = self.plan.desc
+        return 'variant=%s, in=%d, out=%d, inner=%d, groups=%d, mults=%s, attn_res=%s, res_blocks=%d, image=%d, ' \
+               'params=%d (packed arena, libsr3_mi355x)' % (
+                   self.variant, d.in_channel, d.out_channel, d.inner_channel, d.norm_groups,
+                   list(d.channel_mults[:d.n_mults]), list(d.attn_res[:d.n_attn_res]), d.res_blocks, d.image_size,
+                   sum(e['numel'] for e in self.plan.table))

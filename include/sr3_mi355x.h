@@ -1,0 +1,162 @@
+/* libsr3_mi355x.so -- C ABI of the MI355X-native SR3 / DDPM iterative-refinement engine.
+ *
+ * The reference (Janspiry/Image-Super-Resolution-via-Iterative-Refinement) is pure PyTorch and has
+ * no FFI of its own; the drop-in boundary is its Python surface (model.networks.define_G,
+ * GaussianDiffusion, DDPM -- see INTEGRATION.md).  This header is the C layer underneath that
+ * surface: plain pointers and sizes only, no torch types.  Each entry cites the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer named *_dev / every `const float*` tensor argument is a DEVICE pointer
+ *    (tensor.data_ptr()); `stream` is a hipStream_t passed as void* (0 = default stream);
+ *  - all calls are asynchronous on `stream`, never synchronise, never allocate or free device
+ *    memory (workspaces are sized by a query and passed in), and are hipGraph-capturable;
+ *  - return value: 0 ok, >0 a hipError_t, <0 an engine error (SR3_E_*); sr3_last_error() returns a
+ *    thread-local message; no C++ exception crosses the ABI;
+ *  - public tensors (x, cond, eps, z) are NCHW fp32 as in the reference; internal activations are
+ *    NHWC fp32 inside the workspace.
+ */
+#ifndef SR3_MI355X_H
+#define SR3_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR3_ABI_VERSION 1
+
+#define SR3_E_BADARG (-1)
+#define SR3_E_UNSUPPORTED (-2)
+#define SR3_E_ALIGN (-3)
+#define SR3_E_NOMEM (-4)
+#define SR3_E_STATE (-5)
+
+#define SR3_VARIANT_SR3 0  /* model/sr3_modules: continuous noise-level conditioning */
+#define SR3_VARIANT_DDPM 1 /* model/ddpm_modules: integer-timestep conditioning      */
+
+/* Mirrors the arguments of UNet.__init__ (model/sr3_modules/unet.py:162-173,
+ * model/ddpm_modules/unet.py:148-159) as filled by define_G (model/networks.py:91-101). */
+typedef struct sr3_unet_desc {
+  int variant;
+  int in_channel, out_channel, inner_channel, norm_groups;
+  int n_mults;
+  int channel_mults[8];
+  int n_attn_res;
+  int attn_res[8];
+  int res_blocks;
+  int image_size;
+} sr3_unet_desc;
+
+/* One entry of the parameter table: where a reference state_dict tensor lives in the packed
+ * parameter arena.  pack: 0 = copied as is (row-major), 1 = conv weight OIHW -> OHWI. */
+typedef struct sr3_param_info {
+  char name[128]; /* reference key without the "denoise_fn." prefix, e.g. downs.1.res_block.block1.block.3.weight */
+  int ndim;
+  int shape[4];   /* reference shape (OIHW for convs) */
+  int pack;
+  size_t offset;  /* float offset inside the arena */
+  size_t numel;
+} sr3_param_info;
+
+typedef struct sr3_plan sr3_plan;
+
+int sr3_version(void);
+const char* sr3_last_error(void);
+
+/* UNet construction (model/sr3_modules/unet.py:162-233): builds the layer list, the parameter
+ * table and the activation plan.  No device work. */
+int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out);
+void sr3_plan_destroy(sr3_plan* plan);
+int sr3_plan_num_params(const sr3_plan* plan);
+int sr3_plan_param_info(const sr3_plan* plan, int index, sr3_param_info* out);
+size_t sr3_plan_param_floats(const sr3_plan* plan);
+/* ordered list of kernels one forward launches, for inspection / DESIGN.md: returns count */
+int sr3_plan_num_ops(sr3_plan* plan, int batch);
+/* algorithmic FLOPs (contractions only) of one forward for `batch` images */
+double sr3_plan_forward_flops(sr3_plan* plan, int batch);
+/* tuning knobs: key in {"fuse_stats", "tile_cfg", "ksplit", "keep_all"}; returns previous value */
+int sr3_plan_set_option(sr3_plan* plan, const char* key, int value);
+
+/* Debug taps: where each top-level layer output (downs.i / mid.i / ups.i, NHWC) lives inside the
+ * workspace after a forward.  Only meaningful with option keep_all = 1 (no buffer reuse). */
+int sr3_plan_num_taps(sr3_plan* plan);
+int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_t* offset, int* C, int* H, int* W);
+
+/* Workspace bytes for sr3_unet_forward at this batch size (activations, statistics, FiLM table,
+ * split-K slabs). */
+size_t sr3_workspace_bytes(sr3_plan* plan, int batch);
+
+/* UNet.forward (model/sr3_modules/unet.py:235-259, model/ddpm_modules/unet.py:220-243).
+ *   x_nchw    : (B, in_channel - cond_channels, S, S)  the noisy image
+ *   cond_nchw : (B, cond_channels, S, S) or NULL -- the conditioning image; the engine consumes the
+ *               pair as the virtual concat torch.cat([cond, x], 1) (model/sr3_modules/diffusion.py:157)
+ *   noise_level : (B) fp32, SR3 variant (the (B,1) tensor of diffusion.py:153-154), else NULL
+ *   timestep  : (B) int64, DDPM variant, else NULL
+ *   freq      : (inner_channel/2) fp32 frequency table (PositionalEncoding / TimeEmbedding.inv_freq)
+ *   level_table/step_dev : optional graph-replay source of the conditioning value: when step_dev is
+ *               non-NULL the level is level_table[*step_dev + 1] (SR3) or the timestep *step_dev (DDPM)
+ *   params    : packed parameter arena (see sr3_plan_param_info)
+ *   eps_out_nchw : (B, out_channel, S, S) */
+int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
+                     const float* noise_level, const int64_t* timestep, const float* freq,
+                     const float* level_table, const int* step_dev, const float* params,
+                     void* workspace, size_t workspace_bytes, float* eps_out_nchw, int batch,
+                     void* stream);
+
+/* Fused elementwise tail of p_mean_variance + p_sample (model/sr3_modules/diffusion.py:141-149,
+ * 162-174; model/ddpm_modules/diffusion.py:151-198), in place on x:
+ *   x0 = a[t] x - b[t] eps ; clamp(-1,1) ; mean = c1[t] x0 + c2[t] x ; x = mean + sigma[t] z
+ * tables (length T, fp32): a = sqrt_recip_alphas_cumprod, b = sqrt_recipm1_alphas_cumprod,
+ * c1/c2 = posterior_mean_coef1/2, sigma[t] = exp(0.5 posterior_log_variance_clipped[t]), sigma[0] = 0.
+ * t is *step_dev if non-NULL, else t_per_sample[b] if non-NULL, else step_host.  z may be NULL (= 0). */
+int sr3_p_sample_step(float* x_nchw, const float* eps_nchw, const float* z_nchw, const float* tab_a,
+                      const float* tab_b, const float* tab_c1, const float* tab_c2, const float* tab_sigma,
+                      const int* step_dev, const int64_t* t_per_sample, int step_host, int batch,
+                      int elems_per_image, void* stream);
+/* *step_dev -= 1 on the stream (loop counter of p_sample_loop, diffusion.py:193, for graph replay) */
+int sr3_step_decrement(int* step_dev, void* stream);
+
+/* q_sample (model/sr3_modules/diffusion.py:212-219; model/ddpm_modules/diffusion.py:259-267):
+ * out = ca[b] * x0 + cb[b] * z */
+int sr3_q_sample(const float* x0, const float* z, const float* ca, const float* cb, int batch,
+                 int elems_per_image, float* out, void* stream);
+
+/* ---- per-op entry points (unit tests, micro-benchmarks) ------------------------------------ */
+
+/* Block / Conv2d / Downsample / Upsample / res_conv / qkv / out as one implicit-GEMM call:
+ * NHWC in/out, input = virtual concat (src0|src1), optional x2 nearest upsample, stride 1|2,
+ * ksize 1|3 (pad ksize/2), prologue act 0 none | 1 x*scale+shift | 2 silu(x*scale+shift) with
+ * ss[B][Cin][2]; epilogue + bias + film[b*film_stride+n] + residual (res0|res1 concat view).
+ * weights OHWI.  tile_cfg/ksplit 0 = auto.  scratch: split-K slabs (sr3_conv_scratch_bytes). */
+int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
+                 int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,
+                 int act, const float* film, int film_stride, const float* res0, int RC0, const float* res1,
+                 int RC1, float* out, double* out_stats, int tile_cfg, int ksplit, void* scratch,
+                 size_t scratch_bytes, void* stream);
+size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit);
+/* nn.GroupNorm statistics (unet.py:84,119): per-(image, channel) {sum, sumsq} in double of an NHWC
+ * tensor; `stat` ([B][C][2] doubles) must be zero on entry. */
+int sr3_groupnorm_stats_f32(const float* x_nhwc, int B, int HW, int C, double* stat, void* stream);
+/* fold statistics of the concat (stat0|stat1) with gamma/beta into ss[B][C0+C1][2] */
+int sr3_groupnorm_fold_f32(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+                           const float* gamma, const float* beta, float eps, float* ss, void* stream);
+/* SelfAttention core (unet.py:127-139): qkv NHWC [B][N][3C] -> out [B][N][C] */
+int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream);
+/* noise-level / timestep embedding + MLP + all FiLM rows (unet.py:18-50,179-184): see sr3_common.h */
+int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep,
+                       const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* wf, const float* bf, int F, float* temb_scratch, float* film_out,
+                       void* stream);
+/* first conv (NCHW concat in -> NHWC) and final Block (NHWC -> NCHW) */
+int sr3_conv_in_f32(const float* a_nchw, int Ca, const float* b_nchw, int Cb, int B, int H, int W,
+                    const float* w_ohwi, const float* bias, int Cout, float* out_nhwc, void* stream);
+int sr3_conv_out_f32(const float* x_nhwc, const float* ss, int B, int H, int W, int C, const float* w_ohwi,
+                     const float* bias, int Cout, float* out_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SR3_MI355X_H */

@@ -1,0 +1,263 @@
+"""Per-op parity of the HIP kernels (through the C ABI) against float64 CPU references.
+Tolerance: 2e-5 * max(1, |ref|_inf)  (~10x the reference's own fp32 reorder noise)."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from sr3_hip import lib as L                      # noqa: E402
+import gpu_util as G                              # noqa: E402
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # name, B, C0, C1, H, W, Cout, k, stride, ups, act, film, res, bias
+    ('plain3x3', 2, 64, 0, 16, 16, 64, 3, 1, 0, 0, False, False, True),
+    ('gn_silu_film', 2, 64, 0, 16, 16, 128, 3, 1, 0, 2, True, False, True),
+    ('gn_silu_res', 2, 128, 0, 8, 8, 128, 3, 1, 0, 2, False, True, True),
+    ('concat', 2, 64, 32, 16, 16, 64, 3, 1, 0, 2, True, False, True),
+    ('concat_idres', 1, 32, 32, 8, 8, 64, 3, 1, 0, 2, False, 'concat', True),
+    ('stride2', 2, 64, 0, 16, 16, 64, 3, 2, 0, 0, False, False, True),
+    ('upsample', 2, 64, 0, 8, 8, 64, 3, 1, 1, 0, False, False, True),
+    ('k1_affine_nobias', 2, 64, 0, 8, 8, 192, 1, 1, 0, 1, False, False, False),
+    ('k1_res', 2, 96, 0, 8, 8, 64, 1, 1, 0, 0, False, True, True),
+    ('ragged', 3, 24, 0, 10, 10, 40, 3, 1, 0, 2, True, True, True),
+    ('ragged_concat_k1', 3, 8, 12, 6, 10, 24, 1, 1, 0, 0, False, False, True),
+    ('tiny_img', 5, 32, 0, 4, 4, 32, 3, 1, 0, 2, True, True, True),
+    ('deepK', 1, 512, 512, 8, 8, 64, 3, 1, 0, 2, False, False, True),
+]
+
+
+def _make_case(case, seed=1):
+    name, B, C0, C1, H, W, Cout, k, stride, ups, act, film, res, bias = case
+    Cin = C0 + C1
+    src0 = _rand(B, C0, H, W, seed=seed)
+    src1 = _rand(B, C1, H, W, seed=seed + 1) if C1 else None
+    w = _rand(Cout, Cin, k, k, seed=seed + 2, scale=1.0 / math.sqrt(Cin * k * k))
+    kw = dict(ups=ups, stride=stride, act=act)
+    if bias:
+        kw['bias'] = _rand(Cout, seed=seed + 3)
+    if act:
+        ss = torch.stack([_rand(B, Cin, seed=seed + 4) * 0.3 + 1.0, _rand(B, Cin, seed=seed + 5) * 0.3], dim=2)
+        kw['ss'] = ss.contiguous()
+    if film:
+        kw['film'] = _rand(B, Cout, seed=seed + 6)
+    pad = k // 2
+    Ho = ((H << ups) + 2 * pad - k) // stride + 1
+    Wo = ((W << ups) + 2 * pad - k) // stride + 1
+    if res == 'concat':
+        kw['res0'], kw['res1'] = src0, src1
+    elif res:
+        kw['res0'] = _rand(B, Cout, Ho, Wo, seed=seed + 7)
+    return src0, src1, w, kw
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2)])
+def test_conv(case, tile_cfg, ksplit):
+    src0, src1, w, kw = _make_case(case)
+    total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]
+    if ksplit > total:
+        pytest.skip('more splits than k-steps')
+    got, _ = G.conv_call(src0, src1, w, tile_cfg=tile_cfg, ksplit=ksplit, **kw)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    assert not torch.isnan(got).any()
+    G.assert_close(got, ref, what=case[0])
+
+
+@pytest.mark.parametrize('ksplit', [1, 2])
+def test_conv_fused_output_stats(ksplit):
+    case = ('stats', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True)
+    src0, src1, w, kw = _make_case(case)
+    got, st = G.conv_call(src0, src1, w, ksplit=ksplit, want_stats=True, **kw)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    G.assert_close(got, ref)
+    s1 = got.double().sum(dim=(2, 3))
+    s2 = (got.double() ** 2).sum(dim=(2, 3))
+    assert torch.allclose(st[:, :, 0], s1, rtol=1e-9, atol=1e-9)
+    assert torch.allclose(st[:, :, 1], s2, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('B,HW,C', [(2, 256, 64), (3, 100, 24), (2, 16384, 64), (4, 64, 512), (1, 16, 1024)])
+def test_groupnorm_stats_and_fold(B, HW, C):
+    lib = L.load()
+    d = G.dev()
+    x = _rand(B, HW, C, seed=3) * 2 + 0.5
+    xd = x.to(d)
+    st = torch.zeros(B, C, 2, dtype=torch.float64, device=d)
+    L.check(lib.sr3_groupnorm_stats_f32(L.ptr(xd), B, HW, C, L.ptr(st), G.stream()))
+    torch.cuda.synchronize()
+    assert torch.allclose(st[:, :, 0].cpu(), x.double().sum(1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(st[:, :, 1].cpu(), (x.double() ** 2).sum(1), rtol=1e-12, atol=1e-9)
+    # fold as a concat of two halves with groups straddling the seam where possible
+    C0 = C // 2 - 4 if C >= 16 else C
+    C1 = C - C0
+    groups = 4 if C % 4 == 0 else 1
+    gamma, beta = _rand(C, seed=4) * 0.2 + 1, _rand(C, seed=5) * 0.2
+    st0 = st[:, :C0].contiguous()
+    st1 = st[:, C0:].contiguous() if C1 else None
+    ss = torch.empty(B, C, 2, device=d)
+    L.check(lib.sr3_groupnorm_fold_f32(L.ptr(st0), C0, L.ptr(st1), C1, B, HW, groups, L.ptr(gamma.to(d)),
+                                       L.ptr(beta.to(d)), 1e-5, L.ptr(ss), G.stream()))
+    torch.cuda.synchronize()
+    xn = x.permute(0, 2, 1).reshape(B, C, HW, 1)
+    ref = F.group_norm(xn.double(), groups, gamma.double(), beta.double(), eps=1e-5)
+    got = xn.double() * ss[:, :, 0].cpu().double()[:, :, None, None] + ss[:, :, 1].cpu().double()[:, :, None, None]
+    G.assert_close(got, ref, tol=5e-6, what='gn fold')
+
+
+@pytest.mark.parametrize('B,N,C', [(2, 256, 512), (2, 64, 512), (3, 16, 256), (2, 64, 16), (1, 1024, 128)])
+def test_attention(B, N, C):
+    lib = L.load()
+    d = G.dev()
+    qkv = _rand(B, N, 3 * C, seed=7)
+    out = torch.full((B, N, C), float('nan'), device=d)
+    L.check(lib.sr3_attention_f32(L.ptr(qkv.to(d)), B, N, C, L.ptr(out), G.stream()))
+    torch.cuda.synchronize()
+    q, k, v = qkv.double().split(C, dim=2)
+    p = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1)
+    ref = p @ v
+    G.assert_close(out.cpu(), ref, what='attention')
+
+
+@pytest.mark.parametrize('variant', [0, 1])
+def test_film_embed(variant):
+    lib = L.load()
+    d = G.dev()
+    B, inner, Fn = 3, 64, 200
+    w1, b1 = _rand(4 * inner, inner, seed=1) * 0.1, _rand(4 * inner, seed=2) * 0.1
+    w2, b2 = _rand(inner, 4 * inner, seed=3) * 0.1, _rand(inner, seed=4) * 0.1
+    wf, bf = _rand(Fn, inner, seed=5) * 0.1, _rand(Fn, seed=6) * 0.1
+    if variant == 0:
+        level = torch.tensor([0.999, 0.5, 0.013])
+        tstep = None
+        count = inner // 2
+        freq = torch.exp(-math.log(1e4) * (torch.arange(count, dtype=torch.float32) / count))
+        arg = level[:, None] * freq[None]
+    else:
+        level = None
+        tstep = torch.tensor([0, 999, 1999], dtype=torch.long)
+        freq = torch.exp(torch.arange(0, inner, 2, dtype=torch.float32) * (-math.log(10000) / inner))
+        arg = torch.outer(tstep.float(), freq)
+    enc = torch.cat([arg.sin(), arg.cos()], -1).double()
+    h = enc @ w1.double().t() + b1.double()
+    h = h * torch.sigmoid(h)
+    t = h @ w2.double().t() + b2.double()
+    if variant == 1:
+        t = t * torch.sigmoid(t)
+    ref = t @ wf.double().t() + bf.double()
+    g = lambda x: None if x is None else x.to(d)
+    temb = torch.empty(B, inner, device=d)
+    film = torch.empty(B, Fn, device=d)
+    L.check(lib.sr3_film_embed_f32(variant, B, inner, L.ptr(g(level)), L.ptr(g(tstep)), L.ptr(g(freq)), L.ptr(g(w1)),
+                                   L.ptr(g(b1)), L.ptr(g(w2)), L.ptr(g(b2)), L.ptr(g(wf)), L.ptr(g(bf)), Fn,
+                                   L.ptr(temb), L.ptr(film), G.stream()))
+    torch.cuda.synchronize()
+    G.assert_close(film.cpu(), ref, tol=1e-5, what='film')
+
+
+@pytest.mark.parametrize('B,Ca,Cb,H,W,Cout', [(2, 3, 3, 16, 16, 64), (3, 3, 0, 10, 12, 8), (1, 3, 3, 128, 128, 64)])
+def test_conv_in(B, Ca, Cb, H, W, Cout):
+    lib = L.load()
+    d = G.dev()
+    a = _rand(B, Ca, H, W, seed=1)
+    b = _rand(B, Cb, H, W, seed=2) if Cb else None
+    w = _rand(Cout, Ca + Cb, 3, 3, seed=3) * 0.2
+    bias = _rand(Cout, seed=4)
+    out = torch.full((B, H, W, Cout), float('nan'), device=d)
+    L.check(lib.sr3_conv_in_f32(L.ptr(a.to(d)), Ca, L.ptr(None if b is None else b.to(d)), Cb, B, H, W,
+                                L.ptr(G.ohwi(w).to(d)), L.ptr(bias.to(d)), Cout, L.ptr(out), G.stream()))
+    torch.cuda.synchronize()
+    x = a if b is None else torch.cat([a, b], 1)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    G.assert_close(G.nchw(out).cpu(), ref, what='conv_in')
+
+
+@pytest.mark.parametrize('B,H,W,Cc,Cout', [(2, 16, 16, 64, 3), (3, 10, 40, 8, 3), (1, 128, 128, 64, 3)])
+def test_conv_out(B, H, W, Cc, Cout):
+    lib = L.load()
+    d = G.dev()
+    x = _rand(B, Cc, H, W, seed=1)
+    ss = torch.stack([_rand(B, Cc, seed=2) * 0.3 + 1.0, _rand(B, Cc, seed=3) * 0.3], dim=2).contiguous()
+    w = _rand(Cout, Cc, 3, 3, seed=4) * 0.1
+    bias = _rand(Cout, seed=5)
+    out = torch.full((B, Cout, H, W), float('nan'), device=d)
+    L.check(lib.sr3_conv_out_f32(L.ptr(G.nhwc(x).to(d)), L.ptr(ss.to(d)), B, H, W, Cc, L.ptr(G.ohwi(w).to(d)),
+                                 L.ptr(bias.to(d)), Cout, L.ptr(out), G.stream()))
+    torch.cuda.synchronize()
+    ref = G.conv_ref(x, None, w, bias=bias, ss=ss, act=2)
+    G.assert_close(out.cpu(), ref, what='conv_out')
+
+
+def test_p_sample_step_bit_exact():
+    """The fused update must equal the reference's elementwise torch ops bit for bit."""
+    from oracle import sr3_oracle as O
+    lib = L.load()
+    d = G.dev()
+    tab = O.schedule_tables(dict(schedule='linear', n_timestep=50, linear_start=1e-6, linear_end=1e-2))
+    T = tab['num_timesteps']
+    sig = (0.5 * torch.from_numpy(tab['posterior_log_variance_clipped'])).exp()
+    sig[0] = 0
+    tabs = [torch.from_numpy(tab[k]).to(d) for k in ('sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod',
+                                                     'posterior_mean_coef1', 'posterior_mean_coef2')] + [sig.to(d)]
+    B = 3
+    x, eps, z = _rand(B, 3, 16, 16, seed=1), _rand(B, 3, 16, 16, seed=2), _rand(B, 3, 16, 16, seed=3)
+    for t in (T - 1, 17, 0):
+        xd = x.to(d).clone()
+        L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs], None,
+                                      None, t, B, 3 * 16 * 16, G.stream()))
+        torch.cuda.synchronize()
+        ref = O.p_sample_update(tab, x, eps, t, z)
+        assert torch.equal(xd.cpu(), ref), t
+    # per-sample t (DDPM API) and device step counter
+    tps = torch.tensor([0, 5, 49], dtype=torch.long)
+    xd = x.to(d).clone()
+    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs], None,
+                                  L.ptr(tps.to(d)), 0, B, 3 * 16 * 16, G.stream()))
+    torch.cuda.synchronize()
+    for b in range(B):
+        ref = O.p_sample_update(tab, x[b:b + 1], eps[b:b + 1], int(tps[b]), z[b:b + 1])
+        assert torch.equal(xd[b:b + 1].cpu(), ref)
+    step = torch.tensor([17], dtype=torch.int32, device=d)
+    xd = x.to(d).clone()
+    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs],
+                                  L.ptr(step), None, 0, B, 3 * 16 * 16, G.stream()))
+    L.check(lib.sr3_step_decrement(L.ptr(step), G.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), O.p_sample_update(tab, x, eps, 17, z)) and int(step.item()) == 16
+
+
+def test_q_sample_bit_exact():
+    lib = L.load()
+    d = G.dev()
+    B = 4
+    x0, z = _rand(B, 3, 8, 8, seed=1), _rand(B, 3, 8, 8, seed=2)
+    g = torch.rand(B)
+    ca, cb = g, (1 - g ** 2).sqrt()
+    out = torch.empty(B, 3, 8, 8, device=d)
+    L.check(lib.sr3_q_sample(L.ptr(x0.to(d)), L.ptr(z.to(d)), L.ptr(ca.to(d)), L.ptr(cb.to(d)), B, 3 * 64, L.ptr(out),
+                             G.stream()))
+    torch.cuda.synchronize()
+    ref = ca.view(-1, 1, 1, 1) * x0 + cb.view(-1, 1, 1, 1) * z
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_error_convention():
+    lib = L.load()
+    d = G.dev()
+    x = torch.zeros(1, 4, 4, 6, device=d)      # C0 = 6 is not a multiple of 4
+    w = torch.zeros(8, 9, 6, device=d)
+    out = torch.zeros(1, 4, 4, 8, device=d)
+    rc = lib.sr3_conv_f32(L.ptr(x), 6, None, 0, 1, 4, 4, 0, 1, 3, 8, L.ptr(w), None, None, 0, None, 0, None, 0, None, 0,
+                          L.ptr(out), None, 0, 0, None, 0, G.stream())
+    assert rc == -2 and b'multiples of 4' in lib.sr3_last_error()
+    with pytest.raises(L.Sr3Error):
+        L.check(rc)

@@ -1,0 +1,140 @@
+"""UNet / reverse-step / reverse-loop parity of the engine (through the drop-in `model` package and
+the C ABI) against the committed reference vectors (tests/golden) and the CPU oracle.
+
+Stated fp32 tolerances: one forward 2e-5 * max(1, |ref|_inf); full loop 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import DESCS, SCHEDS, CONDITIONAL, load_golden, opt_for      # noqa: E402
+import gpu_util as G                                                     # noqa: E402
+
+NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam']
+
+
+def build(name, **plan_opts):
+    import model as Model
+    opt = opt_for(name, phase='val', gpu=True)
+    m = Model.create_model(opt)
+    g, sd = load_golden(name)
+    m.netG.load_state_dict(sd, strict=True)
+    for k, v in plan_opts.items():
+        m.netG.denoise_fn.plan.set_option(k, v)
+    m.netG.show_progress = False
+    return m, g, sd
+
+
+@pytest.mark.parametrize('name', NAMES)
+@pytest.mark.parametrize('fuse', [0, 1])
+def test_unet_forward_and_layer_taps(name, fuse):
+    m, g, sd = build(name, keep_all=1, fuse_stats=fuse)
+    un = m.netG.denoise_fn
+    d = G.dev()
+    x = torch.from_numpy(g['unet/x']).to(d)
+    t = torch.from_numpy(g['unet/time']).to(d)
+    eps = un(x, t)
+    torch.cuda.synchronize()
+    ws = un._ws.buf
+    off0 = (-ws.data_ptr()) % 256
+    worst = 0.0
+    for (tname, off, C, H, W) in un.plan.taps():
+        B = x.shape[0]
+        raw = ws[off0 + off: off0 + off + B * H * W * C * 4].view(torch.float32).view(B, H, W, C)
+        got = raw.permute(0, 3, 1, 2).cpu()
+        ref = torch.from_numpy(g['unet/tap/' + tname])
+        worst = max(worst, G.assert_close(got, ref, what='%s tap %s' % (name, tname)))
+    G.assert_close(eps.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps')
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_unet_forward_buffer_reuse_matches(name):
+    """The liveness-planned workspace (buffers recycled) gives the same eps as keep_all."""
+    m, g, sd = build(name)
+    un = m.netG.denoise_fn
+    d = G.dev()
+    x = torch.from_numpy(g['unet/x']).to(d)
+    t = torch.from_numpy(g['unet/time']).to(d)
+    e1 = un(x, t).clone()
+    if DESCS[name]['in_channel'] == 6:      # conditioning passed separately == pre-concatenated
+        e2 = un(x[:, 3:].contiguous(), t, cond=x[:, :3].contiguous())
+        assert torch.equal(e1, e2)
+    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_p_sample_steps(name):
+    m, g, sd = build(name)
+    d = G.dev()
+    cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']).to(d)
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    xs = torch.from_numpy(g['step/x']).to(d)
+    T = int(g['meta/T'])
+    for t in sorted({T - 1, T // 2, 0}):
+        if DESCS[name]['variant'] == 'sr3':
+            r = m.netG.p_sample(xs, t, condition_x=sr if cond else None, noise=zs[t])
+        else:
+            r = m.netG.p_sample(xs, torch.full((xs.shape[0],), t, dtype=torch.long, device=d),
+                                condition_x=sr if cond else None, noise=zs[t])
+        G.assert_close(r.cpu(), torch.from_numpy(g['step/%d' % t]), what='%s step %d' % (name, t))
+    assert torch.equal(xs.cpu(), torch.from_numpy(g['step/x']))     # input untouched
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_reverse_loop_injected_noise(name):
+    m, g, sd = build(name)
+    d = G.dev()
+    cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']).to(d)
+    x_T = torch.from_numpy(g['loop/x_T']).to(d)
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    for cont in (True, False):
+        arg = sr if cond else tuple(x_T.shape)
+        r = m.netG.p_sample_loop(arg, continous=cont, x_T=x_T, noise_seq=zs)
+        ref = torch.from_numpy(g['loop/ret_continous' if cont else 'loop/ret_last'])
+        assert tuple(r.shape) == tuple(ref.shape)
+        G.assert_close(r.cpu(), ref, tol=1e-4, what='%s loop cont=%s' % (name, cont))
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_graph_replay_equals_eager(name):
+    """hipGraph replay of the step (device-side counter, in-graph RNG) == the eager loop, same seed."""
+    m, g, sd = build(name)
+    d = G.dev()
+    cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']).to(d)
+    arg = sr if cond else (2, 3, 16, 16)
+    outs = []
+    for use_graph in (False, True, True):
+        m.netG.use_graph = use_graph
+        torch.manual_seed(123)
+        outs.append(m.netG.p_sample_loop(arg, continous=True).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert torch.isfinite(outs[0]).all()
+
+
+def test_api_surface_test_and_visuals():
+    """feed_data -> test(continous) -> get_current_visuals, with the reference's shape quirks."""
+    m, g, sd = build('sr3_tiny')
+    B = 2
+    data = {'HR': torch.from_numpy(g['loop/hr']), 'SR': torch.from_numpy(g['loop/sr']), 'Index': torch.arange(B)}
+    m.feed_data(data)
+    m.test(continous=True)
+    T = int(g['meta/T'])
+    n_snap = sum(1 for i in range(T) if i % (1 | (T // 10)) == 0)
+    assert tuple(m.SR.shape) == (B * (n_snap + 1), 3, 16, 16)
+    vis = m.get_current_visuals(need_LR=False)
+    assert set(vis.keys()) == {'SR', 'INF', 'HR', 'LR'} and vis['SR'].device.type == 'cpu'
+    m.test(continous=False)
+    assert tuple(m.SR.shape) == (3, 16, 16)       # ret_img[-1]: last image of the batch only
+    with pytest.raises(NotImplementedError):
+        m.netG({'HR': data['HR'], 'SR': data['SR']})
+
+
+def test_engine_refuses_cpu():
+    from sr3_hip import lib as L
+    m, g, sd = build('sr3_tiny')
+    with pytest.raises(L.Sr3Error):
+        m.netG.denoise_fn(torch.zeros(1, 6, 16, 16), torch.zeros(1, 1))

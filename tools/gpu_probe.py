@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""GPU probe: per-layer conv sweep (tile config x split-K) on the real SR3 16->128 shapes and a
+full UNet forward timing.  Writes JSON lines to gpurun_out/probe_*.jsonl.  Not part of the product."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd'))
+from sr3_hip import lib as L, engine as E      # noqa: E402
+
+OUT = os.path.join(ROOT, 'gpurun_out')
+os.makedirs(OUT, exist_ok=True)
+
+
+def time_fn(fn, warm=2, iters=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def conv_sweep(B, out_path, quick=False):
+    lib = L.load()
+    d = torch.device('cuda:0')
+    # (name, C0, C1, H (source), Cout, k, stride, ups, act)
+    shapes = [
+        ('128_64_64', 64, 0, 128, 64, 3, 1, 0, 2),
+        ('128_128_64', 64, 64, 128, 64, 3, 1, 0, 2),
+        ('128_192_64', 128, 64, 128, 64, 3, 1, 0, 2),
+        ('up64_128', 128, 0, 64, 128, 3, 1, 1, 0),
+        ('down128_64', 64, 0, 128, 64, 3, 2, 0, 0),
+        ('64_128_128', 128, 0, 64, 128, 3, 1, 0, 2),
+        ('64_384_128', 256, 128, 64, 128, 3, 1, 0, 2),
+        ('32_256_256', 256, 0, 32, 256, 3, 1, 0, 2),
+        ('32_768_256', 512, 256, 32, 256, 3, 1, 0, 2),
+        ('16_512_512', 512, 0, 16, 512, 3, 1, 0, 2),
+        ('16_1024_512', 512, 512, 16, 512, 3, 1, 0, 2),
+        ('8_512_512', 512, 0, 8, 512, 3, 1, 0, 2),
+        ('8_1024_512', 512, 512, 8, 512, 3, 1, 0, 2),
+        ('k1_16_512_1536', 512, 0, 16, 1536, 1, 1, 0, 1),
+        ('k1_16_512_512', 512, 0, 16, 512, 1, 1, 0, 0),
+        ('k1_16_1024_512', 512, 512, 16, 512, 1, 1, 0, 0),
+        ('k1_128_192_64', 128, 64, 128, 64, 1, 1, 0, 0),
+    ]
+    if quick:
+        shapes = shapes[:2] + shapes[7:8] + shapes[9:10] + shapes[11:12]
+    with open(out_path, 'w') as f:
+        for (name, C0, C1, H, Cout, k, stride, ups, act) in shapes:
+            Cin = C0 + C1
+            pad = k // 2
+            Ho = ((H << ups) + 2 * pad - k) // stride + 1
+            s0 = torch.randn(B, H, H, C0, device=d)
+            s1 = torch.randn(B, H, H, C1, device=d) if C1 else None
+            w = torch.randn(Cout, k * k, Cin, device=d) * 0.02
+            bias = torch.randn(Cout, device=d)
+            ss = torch.randn(B, Cin, 2, device=d) if act else None
+            out = torch.empty(B, Ho, Ho, Cout, device=d)
+            flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
+            total_it = ((Cin + 31) // 32) * k * k
+            for cfg in (1, 2, 3, 4):
+                if cfg in (1, 4) and Cout <= 64:
+                    continue
+                for ks in (1, 2, 4, 8):
+                    if ks > 1 and (ks * 4 > total_it):
+                        continue
+                    bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128)}[cfg]
+                    tiles = -(-B * Ho * Ho // bm) * -(-Cout // bn)
+                    if ks > 1 and tiles * ks > 4096:
+                        continue
+                    nb = int(lib.sr3_conv_scratch_bytes(B, Ho, Ho, Cin, Cout, k, cfg, ks))
+                    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
+                    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+                    def run():
+                        L.check(lib.sr3_conv_f32(L.ptr(s0), C0, L.ptr(s1), C1, B, H, H, ups, stride, k, Cout, L.ptr(w),
+                                                 L.ptr(bias), L.ptr(ss), act, None, 0, None, 0, None, 0, L.ptr(out),
+                                                 None, cfg, ks, L.ptr(scratch), nb, st))
+                    ms = time_fn(run)
+                    rec = dict(shape=name, B=B, cfg=cfg, ksplit=ks, tiles=tiles, ms=ms, tflops=flops / ms / 1e9)
+                    f.write(json.dumps(rec) + '\n')
+                    f.flush()
+                    print(rec, flush=True)
+            del s0, s1, w, out, ss
+
+
+def unet_time(B, out_path, fuse):
+    d = torch.device('cuda:0')
+    plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    plan.set_option('fuse_stats', fuse)
+    arena = torch.randn(plan.param_floats, device=d) * 0.02
+    freq = plan.default_freq().to(d)
+    ws = E.Workspace()
+    x = torch.randn(B, 3, 128, 128, device=d)
+    cond = torch.randn(B, 3, 128, 128, device=d)
+    lvl = torch.full((B,), 0.5, device=d)
+    out = torch.empty(B, 3, 128, 128, device=d)
+    fn = lambda: E.unet_forward(plan, arena, freq, ws, x, cond=cond, noise_level=lvl, out=out)
+    ms = time_fn(fn, warm=2, iters=5)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    msg = time_fn(g.replay, warm=2, iters=5)
+    fl = plan.forward_flops(B)
+    rec = dict(what='unet_forward', B=B, fuse_stats=fuse, ms_eager=ms, ms_graph=msg, tflops_graph=fl / msg / 1e9,
+               ops=plan.num_ops(B), ws_gb=plan.workspace_bytes(B) / 1e9, finite=bool(torch.isfinite(out).all()))
+    with open(out_path, 'a') as f:
+        f.write(json.dumps(rec) + '\n')
+    print(rec, flush=True)
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--sweep', action='store_true')
+    ap.add_argument('--quick', action='store_true')
+    ap.add_argument('--unet', action='store_true')
+    a = ap.parse_args()
+    if a.unet:
+        for fuse in (0, 1):
+            unet_time(a.batch, os.path.join(OUT, 'probe_unet.jsonl'), fuse)
+    if a.sweep:
+        conv_sweep(a.batch, os.path.join(OUT, 'probe_conv_B%d.jsonl' % a.batch), a.quick)
