@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- SR3 16->128 sampling throughput of the MI355X engine (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): the SR3 16->128 UNet of config/sr_sr3_16_128.json (inner 64,
+mults 1,2,4,8,8, attention at 16x16, 97.8 M fp32 parameters, random init), batch 16 per GPU,
+T = 2000 linear-beta reverse steps.  A *step* is one reverse step p_sample of the whole batch:
+[z ~ N(0,I)] -> UNet forward -> fused x_{t-1} update -> counter decrement, replayed from one
+hipGraph.  The default --steps 2000 times one complete sample; images/s = N * B / (T * t_step).
+
+One JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (the halo-tile 3x3 conv on v_mfma_f32_32x32x2_f32): algorithmic
+                  FLOPs per launch / average launch duration, measured with HIP events around every
+                  launch of the plan (sr3_unet_forward_profile) right after the timed region.
+  cpu_baseline -- the CPU oracle (oracle/sr3_oracle.py, a port of the reference's algorithm) timed on
+                  this node's host cores on a bounded sample (a few reverse steps at the same batch).
+Multi-GPU: one process per GPU (torch.distributed.run), independent image batches per rank (the
+reverse chains share nothing), no collective in the data path; the timed region is bracketed by
+barrier + synchronize and the MAX over ranks is reported ("scaling": "weak").
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd'))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+
+
+def sr3_16_128_opt(n_timestep=2000):
+    """The `model` subtree of the reference's config/sr_sr3_16_128.json (lines 39-77)."""
+    sched = dict(schedule='linear', n_timestep=n_timestep, linear_start=1e-6, linear_end=1e-2)
+    return {
+        'phase': 'val', 'gpu_ids': [0], 'distributed': False,
+        'path': {'checkpoint': '/tmp', 'resume_state': None},
+        'train': {'optimizer': {'type': 'adam', 'lr': 1e-4}},
+        'model': {
+            'which_model_G': 'sr3', 'finetune_norm': False,
+            'unet': dict(in_channel=6, out_channel=3, inner_channel=64, channel_multiplier=[1, 2, 4, 8, 8],
+                         attn_res=[16], res_blocks=2, dropout=0.2),
+            'beta_schedule': {'train': dict(sched), 'val': dict(sched)},
+            'diffusion': dict(image_size=128, channels=3, conditional=True),
+        },
+    }
+
+
+def cpu_baseline(batch, budget_s=25.0):
+    """Oracle p_sample (UNet forward + update) on the host cores, bounded sample."""
+    from oracle import sr3_oracle as O
+    torch.manual_seed(0)
+    opt = sr3_16_128_opt()
+    desc = O.desc_from_opt(opt)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    # random-init weights with the reference's shapes (values do not matter for timing)
+    from sr3_hip import engine as E
+    plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    sd = {}
+    for e in plan.table:
+        sd['denoise_fn.' + e['name']] = torch.randn(e['shape']) * 0.02
+    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
+    x = torch.randn(batch, 3, 128, 128)
+    sr = torch.rand(batch, 3, 128, 128) * 2 - 1
+    z = torch.randn(batch, 3, 128, 128)
+    times = []
+    with torch.no_grad():
+        t0 = time.time()
+        O.p_sample(sd, desc, tab, x, 1999, z, condition_x=sr)          # warm-up
+        warm = time.time() - t0
+        n = 0
+        start = time.time()
+        while n < 8 and (time.time() - start) + warm < budget_s:
+            t1 = time.time()
+            x = O.p_sample(sd, desc, tab, x, 1998 - n, z, condition_x=sr)
+            times.append(time.time() - t1)
+            n += 1
+    if not times:
+        times = [warm]
+    t_step = sum(times) / len(times)
+    return dict(value=batch / (2000.0 * t_step), unit='images/s', cores=int(torch.get_num_threads()), kind='port',
+                sample='%d reverse steps (oracle p_sample: UNet forward + update) at batch %d after 1 warm-up, '
+                       '%.2f s/step, extrapolated x2000' % (len(times), batch, t_step))
+
+
+def roofline_from_profile(netG, x, cond, level, reps=3):
+    """HIP-event timing of every launch of one forward; aggregates the dominant kernel."""
+    from sr3_hip import lib as L
+    un = netG.denoise_fn
+    plan = un.plan
+    lib = L.load()
+    B = x.shape[0]
+    wsbuf, need = un._ws.get(plan, B, x.device)
+    out = torch.empty(B, 3, 128, 128, device=x.device)
+    max_ops = 4096
+    ms = (C.c_float * max_ops)()
+    kind = (C.c_int * max_ops)()
+    fl = (C.c_double * max_ops)()
+    n = C.c_int()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    agg = {}
+    for r in range(reps + 1):
+        L.check(lib.sr3_unet_forward_profile(plan.handle, L.ptr(x), L.ptr(cond), 3, L.ptr(level), None, L.ptr(un.freq),
+                                             L.ptr(un.arena.data), L.ptr(wsbuf), need, L.ptr(out), B, stream, max_ops,
+                                             ms, kind, fl, C.byref(n)))
+        if r == 0:
+            continue      # warm-up
+        for i in range(n.value):
+            a = agg.setdefault(kind[i], [0.0, 0.0, 0])
+            a[0] += ms[i]
+            a[1] += fl[i]
+            a[2] += 1
+    halo = [agg[k] for k in (55, 56) if k in agg]
+    t_ms = sum(a[0] for a in halo)
+    flops = sum(a[1] for a in halo)
+    launches = sum(a[2] for a in halo)
+    total_ms = sum(a[0] for a in agg.values()) / reps
+    achieved = flops / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    detail = {str(k): dict(ms_per_forward=v[0] / reps, launches_per_forward=v[2] // reps,
+                           tflops=(v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[1] > 0 else None))
+              for k, v in sorted(agg.items())}
+    return dict(bound='mfma', kernel='k_conv3x3_halo (v_mfma_f32_32x32x2_f32)', achieved=achieved,
+                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                avg_launch_us=(t_ms / launches * 1e3 if launches else None),
+                launches_per_forward=launches // reps if reps else 0,
+                flops_per_launch=(flops / launches if launches else None),
+                share_of_forward_time=(t_ms / reps) / total_ms if total_ms > 0 else None,
+                by_op_kind=detail)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE config: 16)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    import model.networks as networks
+    T = 2000
+    torch.manual_seed(0)
+    opt = sr3_16_128_opt(T)
+    netG = networks.define_G(opt).to(dev)
+    netG.set_loss(dev)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], dev)
+    netG.eval()
+    netG.denoise_fn.plan.set_option('fuse_stats', 1)
+    B = a.batch
+    torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
+    cond = (torch.rand(B, 3, 128, 128, device=dev) * 2 - 1)
+    shape = (B, 3, 128, 128)
+    st = netG._loop_state(shape, shape, dev)
+    st['cond'].copy_(cond)
+    st['img'].copy_(torch.randn(shape, device=dev))
+    st['step'].fill_(T - 1)
+    netG._capture(st)
+    graph = st['graph']
+
+    st['step'].fill_(T - 1)
+    # warm-up
+    for _ in range(a.warmup):
+        graph.replay()
+    st['step'].fill_(T - 1)
+    st['img'].normal_()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    done = 0
+    while done < a.steps:                                 # exactly K steps, chains of T
+        n = min(a.steps - done, T)
+        for _ in range(n):
+            graph.replay()
+        done += n
+        if done < a.steps:
+            st['step'].fill_(T - 1)
+            st['img'].normal_()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(st['img']).all().item())
+    ms_per_step = elapsed / a.steps * 1e3
+    images_per_s = world * B / (T * ms_per_step * 1e-3)
+
+    if rank == 0:
+        flops_step = netG.denoise_fn.plan.forward_flops(B)
+        rec = {
+            'metric': 'SR3 16->128 images/sec (2000-step sample)', 'value': images_per_s, 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'SR3 16->128 UNet (reference config/sr_sr3_16_128.json), batch %d per GPU, '
+                                   '2000-step p_sample_loop via hipGraph replay; step = one reverse step of the batch; '
+                                   'images/s = n_gpus*batch/(2000*t_step)' % B,
+                       'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': 128,
+                       'params': 97807491, 'parallelism': 'independent batches per rank (no collective)',
+                       'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
+            'step_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,
+            'step_frac_of_fp32_mfma_peak': flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        }
+        if not a.no_roofline:
+            level = torch.full((B,), 0.5, device=dev)
+            rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+        if not a.no_cpu_baseline and world == 1:
+            rec['cpu_baseline'] = cpu_baseline(B)
+        print(json.dumps(rec), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

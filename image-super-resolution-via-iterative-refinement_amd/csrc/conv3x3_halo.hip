@@ -1,0 +1,343 @@
+// 3x3 stride-1 convolution (the 92 %-of-FLOPs op of the SR3 UNet: `Block` = GroupNorm -> Swish ->
+// Conv3x3, model/sr3_modules/unet.py:80-91, plus Upsample's conv, :58-65) as an implicit GEMM on
+// v_mfma_f32_32x32x2_f32, organised around an LDS-resident *activated halo tile*.
+//
+// Why not plain im2col staging (conv_igemm.hip): on gfx950 the exact-fp32 MFMA runs at the fp32
+// VALU rate and, measured with rocprofv3 (profiles/r01_*), VALU work does not overlap it -- every
+// VALU instruction spent on staging is MFMA time lost.  With im2col staging each input element is
+// loaded, GroupNorm-scaled and SiLU'd once per filter tap (9x); here a workgroup owns a spatial
+// output tile (TH x TW pixels of NB images), stages the (TH+2) x (TW+2) input halo of one 32-channel
+// chunk ONCE (gather for the x2 nearest upsample and the skip-concat seam included, GN+SiLU applied
+// once, zero padding applied after the activation), and the 9 taps read their A fragments from that
+// tile with shifted addresses.  Only the weights of the current tap are re-staged per k-step
+// (double-buffered).  VALU per MFMA drops ~6x.
+//
+// GEMM view per workgroup: out[m][n] += A_tap[m][k] * W_tap[n][k], m = pixel of the tile,
+// k = 32 channels of the chunk.  Waves: WAVES_M x WAVES_N, each a 64 x 64 (MI = NI = 2) block of
+// 32x32 MFMA tiles.  Fragment k-ordering as in conv_igemm.hip (one ds_read_b128 = 4 k-steps).
+// Epilogue: accumulators are transposed through wave-private LDS so that bias / FiLM / residual
+// loads and the NHWC stores are 16-byte wide; optional fused per-(image, channel) statistics of the
+// output for the next GroupNorm (double atomics).
+#include <stdlib.h>
+
+#include "sr3_common.h"
+
+namespace sr3 {
+
+__device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+
+
+template <int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
+  constexpr int LDK = 36, BK = 32;
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int BR = BN / 32;                 // weight loader rows per thread
+  constexpr int HP_MAX = (BM == 128) ? 200 : 324;
+  constexpr int HI = (HP_MAX * 8 + 255) / 256;   // halo float4 items per thread
+  constexpr int WSTAGE = BN * LDK;
+  extern __shared__ f32x4 smem_v[];
+  float* smem = reinterpret_cast<float*>(smem_v);
+  float* halo = smem;                         // [HP][LDK]
+  float* wst = smem + HP_MAX * LDK;           // 2 x [BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kq = tid & 7, lrow = tid >> 3;
+  const int Cin = p.C0 + p.C1;
+  const int H = p.Ho, W = p.Wo;               // stride 1: output dims == virtual input dims
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int tile_n = bid % tiles_n;
+  bid /= tiles_n;
+  const int tw_i = bid % g.tiles_w;
+  bid /= g.tiles_w;
+  const int th_i = bid % g.tiles_h;
+  const int tb_i = bid / g.tiles_h;           // image-group index
+  const int h0 = th_i * g.TH, w0 = tw_i * g.TW, b0 = tb_i * g.NB;
+
+  const int nchunks = (Cin + BK - 1) / BK;
+  const int cper = (nchunks + p.ksplit - 1) / p.ksplit;
+  const int c_begin = blockIdx.y * cper;
+  const int c_end = min(nchunks, c_begin + cper);
+
+  // ---- halo items of this thread (fixed for the whole kernel) --------------------------------
+  // item j covers halo pixel (tid >> 3) + 32 j, channel quad kq of the current chunk
+  int hpix[HI];        // source pixel index ((b*Hs + y)*Ws + x), or -1 when the tap falls in the padding
+  int himg[HI];        // image slot within the tile (for the GN scale/shift select)
+  const int TWp = g.TW + 2;
+#pragma unroll
+  for (int j = 0; j < HI; ++j) {
+    const int hp = lrow + 32 * j;
+    int pix = -1, nb = 0;
+    if (hp < g.HP) {
+      nb = hp / g.HPI;
+      const int r = hp - nb * g.HPI;
+      const int hy = r / TWp, hx = r - hy * TWp;
+      const int ih = h0 + hy - 1, iw = w0 + hx - 1;
+      const int b = b0 + nb;
+      if (b < p.B && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        pix = (b * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+    }
+    hpix[j] = pix;
+    himg[j] = nb;
+  }
+
+  f32x4 rh[HI], rw[BR];
+  f32x4 ssa[2], ssb[2];     // scale/shift of this thread's channel quad for image slots 0 / 1
+  bool wok[BR];
+  bool hvalid = false;      // channel quad of the staged chunk is inside Cin
+
+  auto load_halo = [&](int chunk) {
+    const int c = chunk * BK + kq * 4;
+    hvalid = c < Cin;
+    const int ce = hvalid ? c : 0;
+    const bool second = ce >= p.C0;
+    const float* sp = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
+#pragma unroll
+    for (int j = 0; j < HI; ++j) {
+      const int off = hpix[j] >= 0 ? hpix[j] * sC + cs : 0;
+      rh[j] = *reinterpret_cast<const f32x4*>(sp + off);
+    }
+    if (p.act != 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int b = min(b0 + s, p.B - 1);
+        const float* q = p.ss + (b * Cin + ce) * 2;
+        ssa[s] = *reinterpret_cast<const f32x4*>(q);
+        ssb[s] = *reinterpret_cast<const f32x4*>(q + 4);
+      }
+    }
+  };
+
+  auto store_halo = [&]() {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < HI; ++j) {
+      const int hp = lrow + 32 * j;
+      if (hp < g.HP) {
+        f32x4 v = rh[j];
+        if (p.act != 0) {
+          const f32x4 sa = himg[j] ? ssa[1] : ssa[0];
+          const f32x4 sb = himg[j] ? ssb[1] : ssb[0];
+          v.x = fmaf(v.x, sa.x, sa.y);
+          v.y = fmaf(v.y, sa.z, sa.w);
+          v.z = fmaf(v.z, sb.x, sb.y);
+          v.w = fmaf(v.w, sb.z, sb.w);
+          if (p.act == 2) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
+        }
+        v = (hvalid && hpix[j] >= 0) ? v : zero;
+        *reinterpret_cast<f32x4*>(&halo[hp * LDK + kq * 4]) = v;
+      }
+    }
+  };
+
+  auto load_w = [&](int chunk, int tap) {
+    const int c = chunk * BK + kq * 4;
+    const bool cvalid = c < Cin;
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int n = tile_n * BN + lrow + 32 * j;
+      const bool ok = cvalid && n < p.Cout;
+      wok[j] = ok;
+      const int off = ok ? (n * 9 + tap) * Cin + c : 0;
+      rw[j] = *reinterpret_cast<const f32x4*>(p.w + off);
+    }
+  };
+  auto store_w = [&](int stage) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float* Bw = wst + stage * WSTAGE;
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
+  };
+
+  // ---- MFMA fragments ---------------------------------------------------------------------------
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int kh = (lane >> 5) * 4;
+  int hbase[2];     // halo pixel of this lane's A row for tap (0,0), per 32-row block
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = wave_m * 64 + i * 32 + (lane & 31);
+    const int nb = m >> g.log_thw;
+    const int ty = (m >> g.log_tw) & (g.TH - 1);
+    const int tx = m & (g.TW - 1);
+    hbase[i] = nb * g.HPI + ty * TWp + tx;
+  }
+  const int brow = wave_n * 64 + (lane & 31);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int stage, int tap) {
+    const int fr = tap / 3, fs = tap - fr * 3;
+    const int shift = fr * TWp + fs;
+    const float* Bw = wst + stage * WSTAGE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&halo[(hbase[i] + shift) * LDK + kk * 8 + kh]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bw[(brow + 32 * j) * LDK + kk * 8 + kh]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: chunks (halo restage) x 9 taps (weight restage) ---------------------------------
+  if (c_begin < c_end) {
+    load_halo(c_begin);
+    load_w(c_begin, 0);
+    store_halo();
+    store_w(0);
+    __syncthreads();
+    int stage = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      const bool more_chunks = chunk + 1 < c_end;
+      if (more_chunks) load_halo(chunk + 1);        // in flight across the 9 taps of this chunk
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        const bool last_tap = tap == 8;
+        const bool more = !last_tap || more_chunks;
+        if (more) load_w(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+        if (!(p.dbg & 1)) compute(stage, tap);
+        if (more) store_w(stage ^ 1);
+        if (last_tap && more_chunks) {
+          __syncthreads();                          // every wave is done reading the halo tile
+          store_halo();
+        }
+        __syncthreads();
+        stage ^= 1;
+      }
+    }
+  }
+
+  // ---- epilogue: wave-private LDS transpose, 16-byte bias / FiLM / residual / store ----------------
+  // D layout: reg r of lane l -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+  __syncthreads();                                 // all MFMA reads of LDS are complete
+  constexpr int LDT = 68;                          // 64 + 4 floats
+  float* tr = smem + wave * (32 * LDT);
+  const bool direct = p.ksplit == 1;
+  const size_t Mtot = (size_t)p.B * H * W;
+  float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
+  const int c4 = lane & 15;                        // this lane's float4 column within the 64-wide wave tile
+  const int n = tile_n * BN + wave_n * 64 + c4 * 4;
+  const bool nok = n < p.Cout;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + 32 * j + (lane & 31)] = acc[i][j][r];
+    // wave-private region: LDS executes a wave's instructions in order, so only the data return
+    // has to be awaited (no workgroup barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int mblk = wave_m * 64 + i * 32;                       // first tile row of this 32-row block
+    const int nb = mblk >> g.log_thw;                            // uniform: a block never straddles images
+    const int b = b0 + nb;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    f32x4 film4 = {0.f, 0.f, 0.f, 0.f};
+    if (direct && nok && p.film && b < p.B) film4 = *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int row = (lane >> 4) + 4 * e;
+      const int m = mblk + row;
+      const int ty = (m >> g.log_tw) & (g.TH - 1);
+      const int tx = m & (g.TW - 1);
+      f32x4 v = *reinterpret_cast<const f32x4*>(&tr[row * LDT + c4 * 4]);
+      if (b < p.B && nok) {
+        const size_t pix = ((size_t)b * H + (h0 + ty)) * W + (w0 + tx);
+        if (direct) {
+          v += bias4 + film4;
+          if (p.res0) {
+            if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + pix * p.RC0 + n);
+            else v += *reinterpret_cast<const f32x4*>(p.res1 + pix * p.RC1 + (n - p.RC0));
+          }
+          if (p.ostat) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double dv = (double)v[k]; s1[k] += dv; s2[k] += dv * dv; }
+          }
+        }
+        *reinterpret_cast<f32x4*>(dst + pix * p.Cout + n) = v;
+      }
+    }
+    if (direct && p.ostat) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1[k] += __shfl_xor(s1[k], 16); s1[k] += __shfl_xor(s1[k], 32);
+        s2[k] += __shfl_xor(s2[k], 16); s2[k] += __shfl_xor(s2[k], 32);
+      }
+      if (lane < 16 && nok && b < p.B) {
+        double* o = p.ostat + ((size_t)b * p.Cout + n) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(o + 2 * k, s1[k]); atomicAdd(o + 2 * k + 1, s2[k]); }
+      }
+    }
+  }
+}
+
+// ---- host -----------------------------------------------------------------------------------------
+namespace {
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+template <int WAVES_M, int WAVES_N>
+int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int HP_MAX = (BM == 128) ? 200 : 324;
+  constexpr int smem_main = (HP_MAX * 36 + 2 * BN * 36) * 4;
+  constexpr int smem_epi = 4 * 32 * 68 * 4;
+  constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
+  static bool attr_set = false;
+  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N>;
+  if (!attr_set) {
+    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int groups = (p.B + g.NB - 1) / g.NB;
+  dim3 grid((unsigned)(tiles_n * g.tiles_w * g.tiles_h * groups), p.ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p, g);
+  SR3_LAUNCH_CHECK("k_conv3x3_halo");
+  return SR3_OK;
+}
+}  // namespace
+
+// cfg: 5 = 128(M) x 128(N) tile, 6 = 256 x 64 tile.  Returns false when the problem does not fit.
+bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
+  if (p.ksize != 3 || p.stride != 1) return false;
+  const int H = p.Ho, W = p.Wo;
+  const int BM = cfg == 6 ? 256 : 128;
+  int TW, TH, NB;
+  if (W >= 16) { TW = 16; TH = BM / 16; NB = 1; }
+  else if (W == 8) { TW = 8; TH = 8; NB = BM / 64; }
+  else return false;
+  if (cfg == 6 && W < 16) return false;
+  if (H % TH || W % TW) return false;
+  if (NB > 2) return false;
+  g->TH = TH; g->TW = TW; g->NB = NB;
+  g->log_tw = ilog2(TW); g->log_thw = ilog2(TH * TW);
+  g->tiles_w = W / TW; g->tiles_h = H / TH;
+  g->HPI = (TH + 2) * (TW + 2);
+  g->HP = g->HPI * NB;
+  return g->HP <= (BM == 128 ? 200 : 324);
+}
+
+int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
+  return cfg == 6 ? launch_halo<4, 1>(p, g, st) : launch_halo<2, 2>(p, g, st);
+}
+
+}  // namespace sr3

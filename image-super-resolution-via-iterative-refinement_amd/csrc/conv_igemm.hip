@@ -15,6 +15,8 @@
 // Block = 256 threads = 2x2 waves, tile BM x BN, k-step 32 channels of one filter tap,
 // double-buffered LDS with register staging (global -> VGPR -> [GN/SiLU] -> LDS), one barrier
 // per k-step.  Split-K writes fp32 slabs that a second kernel reduces (deterministic).
+#include <stdlib.h>
+
 #include "sr3_common.h"
 
 namespace sr3 {
@@ -69,9 +71,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   }
 
   f32x4 ra[AR], rw[BR], ssa[AR], ssb[AR];
-  bool aok[AR];
+  bool aok[AR], wok[BR];
   int ss_chunk = -1;
 
+  // Every global load below is UNCONDITIONAL (out-of-range lanes read element 0 of the same
+  // buffer) and the zero mask is applied when the registers are written to LDS, after the MFMA
+  // block: a predicated load would put each load in its own exec-masked branch and drain vmcnt
+  // at the join, exposing the full memory latency every k-step.  32-bit element offsets (host
+  // checks every tensor has < 2^31 elements).
   auto load_global = [&](int it) {
     const int chunk = it / TAPS;
     const int tap = it - chunk * TAPS;
@@ -79,37 +86,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     const int fs = (TAPS == 9) ? tap - fr * 3 : 0;
     const int c = chunk * BK + kq * 4;
     const bool cvalid = c < Cin;
-    const float* sp = p.src0;
-    int sC = p.C0, cs = c;
-    if (c >= p.C0) { sp = p.src1; sC = p.C1; cs = c - p.C0; }
+    const int ce = cvalid ? c : 0;
+    const bool second = ce >= p.C0;
+    const float* sp = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int ih = rih[i] + fr, iw = riw[i] + fs;
       const bool ok = cvalid && rb[i] >= 0 && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
       aok[i] = ok;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t pix = ((size_t)rb[i] * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
-        v = *reinterpret_cast<const f32x4*>(sp + pix * sC + cs);
-      }
-      ra[i] = v;
+      const int pix = (rb[i] * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+      const int off = ok ? pix * sC + cs : 0;
+      ra[i] = *reinterpret_cast<const f32x4*>(sp + off);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const int n = tile_n * BN + lrow + 32 * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cvalid && n < p.Cout) v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)n * TAPS + tap) * Cin + c);
-      rw[j] = v;
+      const bool ok = cvalid && n < p.Cout;
+      wok[j] = ok;
+      const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
+      rw[j] = *reinterpret_cast<const f32x4*>(p.w + off);
     }
     if (p.act != 0 && chunk != ss_chunk) {
       ss_chunk = chunk;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        if (cvalid && rb[i] >= 0) {
-          const float* q = p.ss + ((size_t)rb[i] * Cin + c) * 2;
-          ssa[i] = *reinterpret_cast<const f32x4*>(q);
-          ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
-        }
+        const int be = rb[i] >= 0 ? rb[i] : 0;
+        const float* q = p.ss + (be * Cin + ce) * 2;
+        ssa[i] = *reinterpret_cast<const f32x4*>(q);
+        ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
       }
     }
   };
@@ -117,21 +123,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   auto store_lds = [&](int stage) {
     float* A = smem + stage * STAGE;
     float* Bw = A + BM * LDK;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       f32x4 v = ra[i];
-      if (p.act != 0 && aok[i]) {
+      if (p.act != 0) {
         v.x = fmaf(v.x, ssa[i].x, ssa[i].y);
         v.y = fmaf(v.y, ssa[i].z, ssa[i].w);
         v.z = fmaf(v.z, ssb[i].x, ssb[i].y);
         v.w = fmaf(v.w, ssb[i].z, ssb[i].w);
         if (p.act == 2) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
       }
+      v = aok[i] ? v : zero;     // zero padding is applied AFTER the activation, as the reference does
       *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = rw[j];
+      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
   };
 
   f32x16 acc[MI][NI];
@@ -174,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     for (int it = it0; it < it1; ++it) {
       const int cur = (it - it0) & 1;
       const bool more = it + 1 < it1;
-      if (more) load_global(it + 1);
-      compute(cur);
-      if (more) store_lds(cur ^ 1);
+      if (more && !(p.dbg & 2)) load_global(it + 1);
+      if (!(p.dbg & 1)) compute(cur);
+      if (more && !(p.dbg & 2)) store_lds(cur ^ 1);
       __syncthreads();
     }
   }
@@ -257,15 +265,6 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p) {
       else v += *reinterpret_cast<const f32x4*>(p.res1 + m * p.RC1 + (n - p.RC0));
     }
     *reinterpret_cast<f32x4*>(p.out + m * p.Cout + n) = v;
-    if (p.ostat) {
-      double* o = p.ostat + ((size_t)b * p.Cout + n) * 2;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double dv = (double)v[e];
-        atomicAdd(o + 2 * e, dv);
-        atomicAdd(o + 2 * e + 1, dv * dv);
-      }
-    }
   }
 }
 
@@ -297,9 +296,16 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   const int M = p.B * p.Ho * p.Wo;
   const int Cin = p.C0 + p.C1;
   const int taps = p.ksize * p.ksize;
-  const int total = cdiv(Cin, 32) * taps;
+  const int nchunks = cdiv(Cin, 32);
   if (tile_cfg == 0) {
-    // largest tile that still gives >= ~2 workgroups per CU; fall back to the smallest tile.
+    HaloGeom g;
+    if (p.ksize == 3 && p.stride == 1) {
+      if (p.Cout <= 64 && halo_geometry(p, 6, &g)) tile_cfg = 6;
+      else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
+    }
+  }
+  if (tile_cfg == 0) {
+    // im2col kernel: largest tile that still gives >= ~2 workgroups per CU
     const int order_wide[3] = {1, 2, 3};
     const int order_narrow[2] = {2, 3};
     const int* order = p.Cout > 64 ? order_wide : order_narrow;
@@ -311,17 +317,27 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     }
   }
   if (ksplit == 0) {
-    const TileCfg c = kCfgs[tile_cfg];
-    const long tiles = (long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn);
+    long tiles;
+    int units, min_units;
+    if (tile_cfg >= 5) {
+      HaloGeom g;
+      if (!halo_geometry(p, tile_cfg, &g)) { ksplit = 1; return; }
+      const int bn = tile_cfg == 6 ? 64 : 128;
+      tiles = (long)cdiv(p.Cout, bn) * g.tiles_w * g.tiles_h * cdiv(p.B, g.NB);
+      units = nchunks; min_units = 2;
+    } else {
+      const TileCfg c = kCfgs[tile_cfg];
+      tiles = (long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn);
+      units = nchunks * taps; min_units = 6;
+    }
     int ks = 1;
     if (tiles < 384) {
       ks = (int)((512 + tiles - 1) / tiles);
-      const int max_by_k = total / 6 > 1 ? total / 6 : 1;
-      if (ks > max_by_k) ks = max_by_k;
+      const int cap = units / min_units > 1 ? units / min_units : 1;
+      if (ks > cap) ks = cap;
       if (ks > 16) ks = 16;
     }
-    // no empty splits
-    while (ks > 1 && (long)(ks - 1) * cdiv(total, ks) >= total) --ks;
+    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;   // no empty split
     ksplit = ks;
   }
 }
@@ -348,9 +364,17 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
     set_error("conv: output dims %dx%d inconsistent with input %dx%d k%d s%d", p.Ho, p.Wo, Hi, Wi, p.ksize, p.stride);
     return SR3_E_BADARG;
   }
-  (void)Cin;
+  {
+    const double lim = 2147483647.0;
+    const double e_in = (double)p.B * p.Hs * p.Ws * (double)(p.C0 > p.C1 ? p.C0 : p.C1);
+    const double e_w = (double)p.Cout * p.ksize * p.ksize * (double)Cin;
+    const double e_ss = (double)p.B * Cin * 2.0;
+    if (e_in >= lim || e_w >= lim || e_ss >= lim) { set_error("conv: tensor exceeds 2^31 elements (32-bit offsets)"); return SR3_E_UNSUPPORTED; }
+  }
   conv_pick(p, tile_cfg, ksplit);
   p.ksplit = ksplit;
+  if (ksplit > 1 && p.ostat) { set_error("conv: fused output statistics are not available with split-K"); return SR3_E_UNSUPPORTED; }
+  { static const char* e = getenv("SR3_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (ksplit > 1) {
     const size_t need = (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout * sizeof(float);
     if (!scratch || scratch_bytes < need) { set_error("conv: split-K scratch too small (%zu < %zu)", scratch_bytes, need); return SR3_E_NOMEM; }
@@ -358,6 +382,13 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   int rc;
   const bool k3 = p.ksize == 3;
+  if (tile_cfg >= 5) {
+    HaloGeom g;
+    if (tile_cfg > 6 || !halo_geometry(p, tile_cfg, &g)) { set_error("conv: halo tile_cfg %d does not fit this problem", tile_cfg); return SR3_E_UNSUPPORTED; }
+    const int nchunks = cdiv(Cin, 32);
+    if ((long)(ksplit - 1) * cdiv(nchunks, ksplit) >= nchunks && ksplit > 1) { set_error("conv: ksplit %d leaves an empty split over %d chunks", ksplit, nchunks); return SR3_E_BADARG; }
+    rc = conv3x3_halo_forward(p, tile_cfg, g, st);
+  } else
   switch (tile_cfg) {
     case 1: rc = k3 ? launch_conv<128, 128, 9>(p, st) : launch_conv<128, 128, 1>(p, st); break;
     case 2: rc = k3 ? launch_conv<128, 64, 9>(p, st) : launch_conv<128, 64, 1>(p, st); break;

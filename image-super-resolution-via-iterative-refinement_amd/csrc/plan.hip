@@ -423,7 +423,8 @@ struct Builder {
     o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (o.ksplit > 1) max_scratch = std::max(max_scratch, (size_t)o.ksplit * B * Ho * Wo * Cout * sizeof(float));
-    if (want_stats && P->fuse_stats && ((Ho * Wo) & 7) == 0) {
+    // split-K convs leave the statistics to the (cheap, small-tensor) stand-alone pass
+    if (want_stats && P->fuse_stats && o.ksplit == 1 && ((Ho * Wo) & 7) == 0) {
       o.has_ostat = true; o.f = T[out].stat_off;
       T[out].stats_done = true;
     }
@@ -546,13 +547,17 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
 // ---------------------------------------------------------------------------------------------
 static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_channels, const float* level,
                        const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
-                       const float* params, char* ws, float* eps_out, int B, hipStream_t st) {
+                       const float* params, char* ws, float* eps_out, int B, hipStream_t st,
+                       hipEvent_t* ev = nullptr) {
   const sr3_unet_desc& d = P->d;
+  size_t op_index = 0;
   float* ss = reinterpret_cast<float*>(ws + P->ss_off);
   float* film = reinterpret_cast<float*>(ws + P->film_off);
   int last_hw = 0;
   for (const Op& o : P->ops) {
     int rc = SR3_OK;
+    if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
+    ++op_index;
     switch (o.kind) {
       case OP_MEMSET:
         if (P->stats_bytes) SR3_HIP(hipMemsetAsync(ws + P->stats_off, 0, P->stats_bytes, st));
@@ -614,6 +619,7 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
     }
     if (rc) return rc;
   }
+  if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
   (void)last_hw;
   return SR3_OK;
 }
@@ -707,6 +713,50 @@ int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw
   if (plan->d.variant == SR3_VARIANT_DDPM && !timestep && !step_dev) { set_error("DDPM variant needs timestep or step_dev"); return SR3_E_BADARG; }
   return run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, level_table, step_dev, params,
                      static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream));
+}
+
+int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
+                             const float* noise_level, const int64_t* timestep, const float* freq, const float* params,
+                             void* workspace, size_t workspace_bytes, float* eps_out_nchw, int batch, void* stream,
+                             int max_ops, float* op_ms, int* op_kind, double* op_flops, int* n_ops) {
+  if (!plan || !op_ms || !op_kind || !op_flops || !n_ops) { set_error("null argument"); return SR3_E_BADARG; }
+  if (!cond_nchw) cond_channels = 0;
+  int rc = build_forward(plan, batch, cond_channels);
+  if (rc) return rc;
+  if (workspace_bytes < plan->ws_bytes) { set_error("workspace too small"); return SR3_E_NOMEM; }
+  const int n = (int)plan->ops.size();
+  if (n > max_ops) { set_error("op buffer too small: %d < %d", max_ops, n); return SR3_E_NOMEM; }
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) SR3_HIP(hipEventCreate(&e));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr, nullptr, params,
+                   static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data());
+  if (!rc) {
+    hipError_t e = hipEventSynchronize(ev[n]);
+    if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");
+  }
+  if (!rc) {
+    for (int i = 0; i < n; ++i) {
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      op_ms[i] = ms;
+      const Op& o = plan->ops[i];
+      int kind = (int)o.kind * 10;
+      double fl = 0.0;
+      if (o.kind == OP_CONV) {
+        kind += o.tile_cfg;      // 5x: 51-54 im2col kernel tile configs, 55/56 halo-tile 3x3 kernel
+        const ConvParams& c = o.cp;
+        fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * (double)(c.C0 + c.C1) * c.ksize * c.ksize;
+      } else if (o.kind == OP_ATTN) {
+        fl = 4.0 * batch * (double)o.i0 * (double)o.i0 * o.i1;
+      }
+      op_kind[i] = kind;
+      op_flops[i] = fl;
+    }
+    *n_ops = n;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
 }
 
 int sr3_p_sample_step(float* x, const float* eps, const float* z, const float* ta, const float* tb, const float* tc1,

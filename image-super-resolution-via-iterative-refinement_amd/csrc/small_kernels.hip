@@ -6,6 +6,11 @@
 namespace sr3 {
 
 __device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+// separately rounded product / sum: the empty asm makes the value opaque so hipcc (default
+// -ffp-contract=fast) cannot fuse it into an fma -- bit parity with torch's elementwise ops.
+__device__ __forceinline__ float mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r = a + b; asm volatile("" : "+v"(r)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
 
 // ---------------------------------------------------------------------------------------------
 // per-(image, channel) sum / sum-of-squares in double.  x: NHWC [B][HW][C].
@@ -359,10 +364,10 @@ __global__ __launch_bounds__(256) void k_p_sample_update(float* __restrict__ x, 
     if (z) zv = *reinterpret_cast<const f32x4*>(z + e0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float x0 = __fsub_rn(__fmul_rn(a, xv[k]), __fmul_rn(bb, ev[k]));
+      float x0 = sub_rn(mul_rn(a, xv[k]), mul_rn(bb, ev[k]));
       x0 = fminf(fmaxf(x0, -1.f), 1.f);
-      const float mean = __fadd_rn(__fmul_rn(c1, x0), __fmul_rn(c2, xv[k]));
-      xv[k] = __fadd_rn(mean, __fmul_rn(zv[k], sg));
+      const float mean = add_rn(mul_rn(c1, x0), mul_rn(c2, xv[k]));
+      xv[k] = add_rn(mean, mul_rn(zv[k], sg));
     }
     *reinterpret_cast<f32x4*>(x + e0) = xv;
   }
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(256) void k_q_sample(const float* __restrict__ x0, 
     const f32x4 zv = *reinterpret_cast<const f32x4*>(z + e0);
     f32x4 o;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = __fadd_rn(__fmul_rn(a, xv[k]), __fmul_rn(s, zv[k]));
+    for (int k = 0; k < 4; ++k) o[k] = add_rn(mul_rn(a, xv[k]), mul_rn(s, zv[k]));
     *reinterpret_cast<f32x4*>(out + e0) = o;
   }
 }

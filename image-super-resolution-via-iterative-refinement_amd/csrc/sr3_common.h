@@ -55,14 +55,24 @@ struct ConvParams {
   float* partial;      // split-K scratch [ksplit][M][Cout] (ksplit > 1)
   int ksplit;
   double* ostat;       // optional: per-(b, n) {sum, sumsq} accumulators of the OUTPUT (fused GN stats)
+  int dbg;             // profiling ablations only (env SR3_CONV_DBG): 1 = skip MFMA, 2 = skip staging
 };
 
-// tile_cfg: 0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 ; ksplit: 0 = auto
+// tile_cfg: 0 = auto; im2col-staged implicit GEMM: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128;
+// halo-tile 3x3 stride-1 kernel: 5 = 128x128, 6 = 256(M)x64(N).  ksplit: 0 = auto
 int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_scratch,
                  size_t splitk_scratch_bytes, hipStream_t st);
 // scratch bytes the auto heuristic may ask for (upper bound) for this problem
 size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
+struct HaloGeom {
+  int TH, TW, NB;          // spatial tile per image, images per workgroup tile (TH*TW*NB = BM)
+  int log_tw, log_thw;     // log2(TW), log2(TH*TW)
+  int tiles_w, tiles_h;    // tiles per image
+  int HPI, HP;             // halo pixels per image / per workgroup
+};
+bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g);
+int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
 // per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]; stat must be zeroed.

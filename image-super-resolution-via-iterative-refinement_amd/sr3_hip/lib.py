@@ -46,6 +46,7 @@ SIGNATURES = {
     'sr3_plan_tap_info': (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_Z), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     'sr3_workspace_bytes': (_Z, [_P, _I]),
     'sr3_unet_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
+    'sr3_unet_forward_profile': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P, _I, _P, _P, _P, _P]),
     'sr3_p_sample_step': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'sr3_step_decrement': (_I, [_P, _P]),
     'sr3_q_sample': (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),

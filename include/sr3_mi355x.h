@@ -106,6 +106,16 @@ int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw
                      void* workspace, size_t workspace_bytes, float* eps_out_nchw, int batch,
                      void* stream);
 
+/* Same forward, run eagerly with a hipEvent pair around every launch of the plan (events are
+ * recorded on `stream`).  Measurement aid for bench.py's roofline leg; not capturable.
+ * op_kind: OpKind*10 (+ tile_cfg for convs: 51..54 im2col implicit GEMM, 55/56 halo-tile 3x3);
+ * op_flops: algorithmic FLOPs of contractions (0 for the HBM-bound helpers). */
+int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
+                             const float* noise_level, const int64_t* timestep, const float* freq,
+                             const float* params, void* workspace, size_t workspace_bytes, float* eps_out_nchw,
+                             int batch, void* stream, int max_ops, float* op_ms, int* op_kind, double* op_flops,
+                             int* n_ops);
+
 /* Fused elementwise tail of p_mean_variance + p_sample (model/sr3_modules/diffusion.py:141-149,
  * 162-174; model/ddpm_modules/diffusion.py:151-198), in place on x:
  *   x0 = a[t] x - b[t] eps ; clamp(-1,1) ; mean = c1[t] x0 + c2[t] x ; x = mean + sigma[t] z

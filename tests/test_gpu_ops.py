@@ -33,6 +33,9 @@ CONV_CASES = [
     ('ragged_concat_k1', 3, 8, 12, 6, 10, 24, 1, 1, 0, 0, False, False, True),
     ('tiny_img', 5, 32, 0, 4, 4, 32, 3, 1, 0, 2, True, True, True),
     ('deepK', 1, 512, 512, 8, 8, 64, 3, 1, 0, 2, False, False, True),
+    ('halo_oddB', 3, 32, 0, 8, 8, 64, 3, 1, 0, 2, True, True, True),
+    ('halo_32x32_up', 1, 64, 0, 16, 16, 128, 3, 1, 1, 2, True, True, True),
+    ('halo_concat_seam', 2, 48, 16, 16, 32, 96, 3, 1, 0, 2, False, 'res', True),
 ]
 
 
@@ -61,23 +64,34 @@ def _make_case(case, seed=1):
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2)])
+@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2), (5, 1), (6, 1), (5, 2),
+                                             (6, 2)])
 def test_conv(case, tile_cfg, ksplit):
     src0, src1, w, kw = _make_case(case)
     total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]
     if ksplit > total:
         pytest.skip('more splits than k-steps')
-    got, _ = G.conv_call(src0, src1, w, tile_cfg=tile_cfg, ksplit=ksplit, **kw)
+    try:
+        got, _ = G.conv_call(src0, src1, w, tile_cfg=tile_cfg, ksplit=ksplit, **kw)
+    except L.Sr3Error as e:
+        if tile_cfg >= 5 and ('does not fit' in str(e) or 'empty split' in str(e)):
+            pytest.skip('halo kernel does not cover this shape')
+        raise
     ref = G.conv_ref(src0, src1, w, **kw)
     assert not torch.isnan(got).any()
     G.assert_close(got, ref, what=case[0])
 
 
 @pytest.mark.parametrize('ksplit', [1, 2])
-def test_conv_fused_output_stats(ksplit):
+@pytest.mark.parametrize('tile_cfg', [0, 3, 5])
+def test_conv_fused_output_stats(ksplit, tile_cfg):
     case = ('stats', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True)
     src0, src1, w, kw = _make_case(case)
-    got, st = G.conv_call(src0, src1, w, ksplit=ksplit, want_stats=True, **kw)
+    if ksplit > 1:      # split-K convs leave the statistics to the stand-alone pass
+        with pytest.raises(L.Sr3Error):
+            G.conv_call(src0, src1, w, ksplit=ksplit, tile_cfg=tile_cfg, want_stats=True, **kw)
+        return
+    got, st = G.conv_call(src0, src1, w, ksplit=ksplit, tile_cfg=tile_cfg, want_stats=True, **kw)
     ref = G.conv_ref(src0, src1, w, **kw)
     G.assert_close(got, ref)
     s1 = got.double().sum(dim=(2, 3))
@@ -105,8 +119,9 @@ def test_groupnorm_stats_and_fold(B, HW, C):
     st0 = st[:, :C0].contiguous()
     st1 = st[:, C0:].contiguous() if C1 else None
     ss = torch.empty(B, C, 2, device=d)
-    L.check(lib.sr3_groupnorm_fold_f32(L.ptr(st0), C0, L.ptr(st1), C1, B, HW, groups, L.ptr(gamma.to(d)),
-                                       L.ptr(beta.to(d)), 1e-5, L.ptr(ss), G.stream()))
+    gd, bd = gamma.to(d), beta.to(d)          # keep device copies alive across the async call
+    L.check(lib.sr3_groupnorm_fold_f32(L.ptr(st0), C0, L.ptr(st1), C1, B, HW, groups, L.ptr(gd),
+                                       L.ptr(bd), 1e-5, L.ptr(ss), G.stream()))
     torch.cuda.synchronize()
     xn = x.permute(0, 2, 1).reshape(B, C, HW, 1)
     ref = F.group_norm(xn.double(), groups, gamma.double(), beta.double(), eps=1e-5)
@@ -120,7 +135,8 @@ def test_attention(B, N, C):
     d = G.dev()
     qkv = _rand(B, N, 3 * C, seed=7)
     out = torch.full((B, N, C), float('nan'), device=d)
-    L.check(lib.sr3_attention_f32(L.ptr(qkv.to(d)), B, N, C, L.ptr(out), G.stream()))
+    qd = qkv.to(d)
+    L.check(lib.sr3_attention_f32(L.ptr(qd), B, N, C, L.ptr(out), G.stream()))
     torch.cuda.synchronize()
     q, k, v = qkv.double().split(C, dim=2)
     p = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1)
@@ -157,8 +173,8 @@ def test_film_embed(variant):
     g = lambda x: None if x is None else x.to(d)
     temb = torch.empty(B, inner, device=d)
     film = torch.empty(B, Fn, device=d)
-    L.check(lib.sr3_film_embed_f32(variant, B, inner, L.ptr(g(level)), L.ptr(g(tstep)), L.ptr(g(freq)), L.ptr(g(w1)),
-                                   L.ptr(g(b1)), L.ptr(g(w2)), L.ptr(g(b2)), L.ptr(g(wf)), L.ptr(g(bf)), Fn,
+    dv = [g(t_) for t_ in (level, tstep, freq, w1, b1, w2, b2, wf, bf)]    # held until after the sync
+    L.check(lib.sr3_film_embed_f32(variant, B, inner, *[L.ptr(t_) for t_ in dv], Fn,
                                    L.ptr(temb), L.ptr(film), G.stream()))
     torch.cuda.synchronize()
     G.assert_close(film.cpu(), ref, tol=1e-5, what='film')
@@ -173,8 +189,9 @@ def test_conv_in(B, Ca, Cb, H, W, Cout):
     w = _rand(Cout, Ca + Cb, 3, 3, seed=3) * 0.2
     bias = _rand(Cout, seed=4)
     out = torch.full((B, H, W, Cout), float('nan'), device=d)
-    L.check(lib.sr3_conv_in_f32(L.ptr(a.to(d)), Ca, L.ptr(None if b is None else b.to(d)), Cb, B, H, W,
-                                L.ptr(G.ohwi(w).to(d)), L.ptr(bias.to(d)), Cout, L.ptr(out), G.stream()))
+    ad, bd, wd, biasd = a.to(d), (None if b is None else b.to(d)), G.ohwi(w).to(d), bias.to(d)
+    L.check(lib.sr3_conv_in_f32(L.ptr(ad), Ca, L.ptr(bd), Cb, B, H, W, L.ptr(wd), L.ptr(biasd), Cout, L.ptr(out),
+                                G.stream()))
     torch.cuda.synchronize()
     x = a if b is None else torch.cat([a, b], 1)
     ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
@@ -190,8 +207,9 @@ def test_conv_out(B, H, W, Cc, Cout):
     w = _rand(Cout, Cc, 3, 3, seed=4) * 0.1
     bias = _rand(Cout, seed=5)
     out = torch.full((B, Cout, H, W), float('nan'), device=d)
-    L.check(lib.sr3_conv_out_f32(L.ptr(G.nhwc(x).to(d)), L.ptr(ss.to(d)), B, H, W, Cc, L.ptr(G.ohwi(w).to(d)),
-                                 L.ptr(bias.to(d)), Cout, L.ptr(out), G.stream()))
+    xd, ssd, wd, biasd = G.nhwc(x).to(d), ss.to(d), G.ohwi(w).to(d), bias.to(d)
+    L.check(lib.sr3_conv_out_f32(L.ptr(xd), L.ptr(ssd), B, H, W, Cc, L.ptr(wd), L.ptr(biasd), Cout, L.ptr(out),
+                                 G.stream()))
     torch.cuda.synchronize()
     ref = G.conv_ref(x, None, w, bias=bias, ss=ss, act=2)
     G.assert_close(out.cpu(), ref, what='conv_out')
@@ -210,9 +228,10 @@ def test_p_sample_step_bit_exact():
                                                      'posterior_mean_coef1', 'posterior_mean_coef2')] + [sig.to(d)]
     B = 3
     x, eps, z = _rand(B, 3, 16, 16, seed=1), _rand(B, 3, 16, 16, seed=2), _rand(B, 3, 16, 16, seed=3)
+    ed, zd = eps.to(d), z.to(d)
     for t in (T - 1, 17, 0):
         xd = x.to(d).clone()
-        L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs], None,
+        L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(ed), L.ptr(zd), *[L.ptr(t_) for t_ in tabs], None,
                                       None, t, B, 3 * 16 * 16, G.stream()))
         torch.cuda.synchronize()
         ref = O.p_sample_update(tab, x, eps, t, z)
@@ -220,15 +239,16 @@ def test_p_sample_step_bit_exact():
     # per-sample t (DDPM API) and device step counter
     tps = torch.tensor([0, 5, 49], dtype=torch.long)
     xd = x.to(d).clone()
-    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs], None,
-                                  L.ptr(tps.to(d)), 0, B, 3 * 16 * 16, G.stream()))
+    tpd = tps.to(d)
+    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(ed), L.ptr(zd), *[L.ptr(t_) for t_ in tabs], None,
+                                  L.ptr(tpd), 0, B, 3 * 16 * 16, G.stream()))
     torch.cuda.synchronize()
     for b in range(B):
         ref = O.p_sample_update(tab, x[b:b + 1], eps[b:b + 1], int(tps[b]), z[b:b + 1])
         assert torch.equal(xd[b:b + 1].cpu(), ref)
     step = torch.tensor([17], dtype=torch.int32, device=d)
     xd = x.to(d).clone()
-    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(eps.to(d)), L.ptr(z.to(d)), *[L.ptr(t_) for t_ in tabs],
+    L.check(lib.sr3_p_sample_step(L.ptr(xd), L.ptr(ed), L.ptr(zd), *[L.ptr(t_) for t_ in tabs],
                                   L.ptr(step), None, 0, B, 3 * 16 * 16, G.stream()))
     L.check(lib.sr3_step_decrement(L.ptr(step), G.stream()))
     torch.cuda.synchronize()
@@ -243,8 +263,8 @@ def test_q_sample_bit_exact():
     g = torch.rand(B)
     ca, cb = g, (1 - g ** 2).sqrt()
     out = torch.empty(B, 3, 8, 8, device=d)
-    L.check(lib.sr3_q_sample(L.ptr(x0.to(d)), L.ptr(z.to(d)), L.ptr(ca.to(d)), L.ptr(cb.to(d)), B, 3 * 64, L.ptr(out),
-                             G.stream()))
+    dv = [x0.to(d), z.to(d), ca.to(d), cb.to(d)]
+    L.check(lib.sr3_q_sample(*[L.ptr(t_) for t_ in dv], B, 3 * 64, L.ptr(out), G.stream()))
     torch.cuda.synchronize()
     ref = ca.view(-1, 1, 1, 1) * x0 + cb.view(-1, 1, 1, 1) * z
     assert torch.equal(out.cpu(), ref)

@@ -31,7 +31,7 @@ def time_fn(fn, warm=2, iters=5):
     return s.elapsed_time(e) / iters
 
 
-def conv_sweep(B, out_path, quick=False):
+def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2, 4, 8)):
     lib = L.load()
     d = torch.device('cuda:0')
     # (name, C0, C1, H (source), Cout, k, stride, ups, act)
@@ -54,6 +54,8 @@ def conv_sweep(B, out_path, quick=False):
         ('k1_16_1024_512', 512, 512, 16, 512, 1, 1, 0, 0),
         ('k1_128_192_64', 128, 64, 128, 64, 1, 1, 0, 0),
     ]
+    if only:
+        shapes = [s_ for s_ in shapes if s_[0] in only]
     if quick:
         shapes = shapes[:2] + shapes[7:8] + shapes[9:10] + shapes[11:12]
     with open(out_path, 'w') as f:
@@ -69,13 +71,17 @@ def conv_sweep(B, out_path, quick=False):
             out = torch.empty(B, Ho, Ho, Cout, device=d)
             flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
             total_it = ((Cin + 31) // 32) * k * k
-            for cfg in (1, 2, 3, 4):
+            for cfg in cfgs:
                 if cfg in (1, 4) and Cout <= 64:
                     continue
-                for ks in (1, 2, 4, 8):
+                if cfg >= 5 and (k != 3 or stride != 1):
+                    continue
+                for ks in kss:
                     if ks > 1 and (ks * 4 > total_it):
                         continue
-                    bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128)}[cfg]
+                    if cfg >= 5 and ks > 1 and ks * 2 > (Cin + 31) // 32:
+                        continue
+                    bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 128), 6: (256, 64)}[cfg]
                     tiles = -(-B * Ho * Ho // bm) * -(-Cout // bn)
                     if ks > 1 and tiles * ks > 4096:
                         continue
@@ -87,7 +93,11 @@ def conv_sweep(B, out_path, quick=False):
                         L.check(lib.sr3_conv_f32(L.ptr(s0), C0, L.ptr(s1), C1, B, H, H, ups, stride, k, Cout, L.ptr(w),
                                                  L.ptr(bias), L.ptr(ss), act, None, 0, None, 0, None, 0, L.ptr(out),
                                                  None, cfg, ks, L.ptr(scratch), nb, st))
-                    ms = time_fn(run)
+                    try:
+                        ms = time_fn(run)
+                    except L.Sr3Error as e:
+                        print('skip', name, cfg, ks, str(e)[:80], flush=True)
+                        continue
                     rec = dict(shape=name, B=B, cfg=cfg, ksplit=ks, tiles=tiles, ms=ms, tflops=flops / ms / 1e9)
                     f.write(json.dumps(rec) + '\n')
                     f.flush()
@@ -126,9 +136,15 @@ if __name__ == '__main__':
     ap.add_argument('--sweep', action='store_true')
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--unet', action='store_true')
+    ap.add_argument('--only', default='')
+    ap.add_argument('--cfgs', default='1,2,3,4')
+    ap.add_argument('--kss', default='1,2,4,8')
+    ap.add_argument('--tag', default='')
     a = ap.parse_args()
     if a.unet:
         for fuse in (0, 1):
             unet_time(a.batch, os.path.join(OUT, 'probe_unet.jsonl'), fuse)
     if a.sweep:
-        conv_sweep(a.batch, os.path.join(OUT, 'probe_conv_B%d.jsonl' % a.batch), a.quick)
+        conv_sweep(a.batch, os.path.join(OUT, 'probe_conv_B%d%s.jsonl' % (a.batch, a.tag)), a.quick,
+                   only=[x for x in a.only.split(',') if x] or None, cfgs=[int(x) for x in a.cfgs.split(',')],
+                   kss=[int(x) for x in a.kss.split(',')])
