@@ -50,13 +50,29 @@ def sr3_16_128_opt(n_timestep=2000):
     }
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads
+
+
 def cpu_baseline(batch, budget_s=25.0):
     """Oracle p_sample (UNet forward + update) on the host cores, bounded sample."""
     from oracle import sr3_oracle as O
     torch.manual_seed(0)
     opt = sr3_16_128_opt()
     desc = O.desc_from_opt(opt)
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     # random-init weights with the reference's shapes (values do not matter for timing)
     from sr3_hip import engine as E
@@ -71,11 +87,11 @@ def cpu_baseline(batch, budget_s=25.0):
     times = []
     with torch.no_grad():
         t0 = time.time()
-        O.p_sample(sd, desc, tab, x, 1999, z, condition_x=sr)          # warm-up
+        O.p_sample(sd, desc, tab, x[:1], 1999, z[:1], condition_x=sr[:1])   # warm-up (1 image: allocator, oneDNN)
         warm = time.time() - t0
         n = 0
         start = time.time()
-        while n < 8 and (time.time() - start) + warm < budget_s:
+        while n < 8 and (n == 0 or (time.time() - start) * (n + 1) / n + warm < budget_s):
             t1 = time.time()
             x = O.p_sample(sd, desc, tab, x, 1998 - n, z, condition_x=sr)
             times.append(time.time() - t1)

@@ -7,13 +7,21 @@
 // strip S[32][N] lives in LDS (no online softmax): phase 1 fills it with exact-fp32 MFMA
 // (v_mfma_f32_32x32x2_f32, each wave a 32-key block), phase 2 does the row softmax in place,
 // phase 3 multiplies the strip with V (each wave a 32-channel block of a 128-channel panel).
+// Q/K/V tiles are register-prefetched one step ahead (unconditional loads, masks applied at the
+// LDS write) and double-buffered in LDS when the strip leaves room (NSTAGE = 2).  When the grid
+// would leave CUs idle, the channel panels of phase 3 are split over gridDim.z workgroups (each
+// recomputes the cheap score strip).
 #include "sr3_common.h"
 
 namespace sr3 {
 
 constexpr int AT_LDK = 36;    // Q/K staging row stride (32 + 4 pad floats)
 constexpr int AT_LDV = 132;   // V staging row stride (128 + 4)
+constexpr int AT_QK_STAGE = (32 + 128) * AT_LDK;
+constexpr int AT_V_STAGE = 32 * AT_LDV;
+constexpr int AT_STAGE = AT_QK_STAGE > AT_V_STAGE ? AT_QK_STAGE : AT_V_STAGE;
 
+template <int NSTAGE>
 __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, int N, int C,
                                                     float* __restrict__ out) {
   extern __shared__ f32x4 smem_v[];
@@ -21,44 +29,61 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   const int Npad = (N + 31) & ~31;
   const int LDS_S = Npad + 4;
   float* S = smem;                      // [32][LDS_S]
-  float* stg = smem + 32 * LDS_S;       // staging union
-  float* Qs = stg;                      // [32][AT_LDK]
-  float* Ks = stg + 32 * AT_LDK;        // [128][AT_LDK]
-  float* Vs = stg;                      // [32][AT_LDV]
+  float* stg = smem + 32 * LDS_S;       // NSTAGE staging buffers
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int m0 = blockIdx.x * 32;
-  const size_t rowstride = (size_t)3 * C;
+  const int rowstride = 3 * C;
   const float* base = qkv + (size_t)b * N * rowstride;
   const int kq = tid & 7, lrow = tid >> 3;        // loaders: 8 float4 per 32-channel row
   const int kh = (lane >> 5) * 4;
-  const float inv_div = sqrtf((float)C);
+  const float sqrt_c = sqrtf((float)C);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
   // ---------------- phase 1: S = Q K^T / sqrt(C) ----------------
-  for (int kb = 0; kb < Npad; kb += 128) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool wave_active = (kb + wave * 32) < Npad;
-    for (int c0 = 0; c0 < C; c0 += 32) {
-      const int c = c0 + kq * 4;
-      __syncthreads();
-      {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int m = m0 + lrow;
-        if (m < N && c < C) v = *reinterpret_cast<const f32x4*>(base + (size_t)m * rowstride + c);
-        *reinterpret_cast<f32x4*>(&Qs[lrow * AT_LDK + kq * 4]) = v;
-      }
+  {
+    const int nc = (C + 31) / 32;
+    const int nsteps = (Npad / 128 + ((Npad & 127) ? 1 : 0)) * nc;
+    f32x4 rq, rk[4];
+    bool qok, kok[4];
+    auto load = [&](int s) {
+      const int kb = (s / nc) * 128;
+      const int c = (s % nc) * 32 + kq * 4;
+      const bool cv = c < C;
+      const int m = m0 + lrow;
+      qok = cv && m < N;
+      rq = *reinterpret_cast<const f32x4*>(base + (qok ? m * rowstride + c : 0));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int key = kb + lrow + 32 * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (key < N && c < C) v = *reinterpret_cast<const f32x4*>(base + (size_t)key * rowstride + C + c);
-        *reinterpret_cast<f32x4*>(&Ks[(lrow + 32 * i) * AT_LDK + kq * 4]) = v;
+        kok[i] = cv && key < N;
+        rk[i] = *reinterpret_cast<const f32x4*>(base + (kok[i] ? key * rowstride + C + c : 0));
       }
-      __syncthreads();
+    };
+    auto store = [&](int st) {
+      float* Qs = stg + st * AT_STAGE;
+      float* Ks = Qs + 32 * AT_LDK;
+      *reinterpret_cast<f32x4*>(&Qs[lrow * AT_LDK + kq * 4]) = qok ? rq : zero;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(&Ks[(lrow + 32 * i) * AT_LDK + kq * 4]) = kok[i] ? rk[i] : zero;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = (NSTAGE == 2) ? (s & 1) : 0;
+      const bool more = s + 1 < nsteps;
+      if (more) load(s + 1);
+      const int kb = (s / nc) * 128;
+      const bool wave_active = (kb + wave * 32) < Npad;
       if (wave_active) {
+        const float* Qs = stg + cur * AT_STAGE;
+        const float* Ks = Qs + 32 * AT_LDK;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(&Qs[(lane & 31) * AT_LDK + kk * 8 + kh]);
@@ -66,18 +91,21 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], k4[q], acc, 0, 0, 0);
         }
-      }
-    }
-    if (wave_active) {
-      const int key = kb + wave * 32 + (lane & 31);
+        if ((s % nc) == nc - 1) {           // last channel chunk of this key block: emit the scores
+          const int key = kb + wave * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        S[row * LDS_S + key] = acc[r] / inv_div;
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            S[row * LDS_S + key] = acc[r] / sqrt_c;
+            acc[r] = 0.f;
+          }
+        }
       }
+      if (NSTAGE == 1) __syncthreads();
+      if (more) store((NSTAGE == 2) ? (cur ^ 1) : 0);
+      __syncthreads();
     }
   }
-  __syncthreads();
 
   // ---------------- phase 2: row softmax over the N valid keys ----------------
   {
@@ -98,25 +126,50 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
   __syncthreads();
 
-  // ---------------- phase 3: O = P V ----------------
-  for (int cp = 0; cp < C; cp += 128) {
+  // ---------------- phase 3: O = P V  (this workgroup's share of the 128-channel panels) --------
+  {
+    const int npan = (C + 127) / 128;
+    const int pan_per = (npan + gridDim.z - 1) / gridDim.z;
+    const int pan0 = blockIdx.z * pan_per;
+    const int pan1 = min(npan, pan0 + pan_per);
+    const int nk = Npad / 32;
+    const int nsteps = (pan1 - pan0) * nk;
+    f32x4 rv[4];
+    bool vok[4];
+    auto load = [&](int s) {
+      const int cp = (pan0 + s / nk) * 128;
+      const int k0 = (s % nk) * 32;
+      const int c = cp + (tid & 31) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = k0 + (tid >> 5) + 8 * i;
+        vok[i] = key < N && c < C;
+        rv[i] = *reinterpret_cast<const f32x4*>(base + (vok[i] ? key * rowstride + 2 * C + c : 0));
+      }
+    };
+    auto store = [&](int st) {
+      float* Vs = stg + st * AT_STAGE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(&Vs[((tid >> 5) + 8 * i) * AT_LDV + (tid & 31) * 4]) = vok[i] ? rv[i] : zero;
+    };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const bool wave_active = (cp + wave * 32) < C;
-    for (int k0 = 0; k0 < Npad; k0 += 32) {
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kr = (tid >> 5) + 8 * i;         // key row within the chunk
-        const int c = cp + (tid & 31) * 4;
-        const int key = k0 + kr;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (key < N && c < C) v = *reinterpret_cast<const f32x4*>(base + (size_t)key * rowstride + 2 * C + c);
-        *reinterpret_cast<f32x4*>(&Vs[kr * AT_LDV + (tid & 31) * 4]) = v;
-      }
-      __syncthreads();
+    if (nsteps > 0) {
+      load(0);
+      store(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = (NSTAGE == 2) ? (s & 1) : 0;
+      const bool more = s + 1 < nsteps;
+      if (more) load(s + 1);
+      const int cp = (pan0 + s / nk) * 128;
+      const int k0 = (s % nk) * 32;
+      const bool wave_active = (cp + wave * 32) < C;
       if (wave_active) {
+        const float* Vs = stg + cur * AT_STAGE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const f32x4 a = *reinterpret_cast<const f32x4*>(&S[(lane & 31) * LDS_S + k0 + kk * 8 + kh]);
@@ -126,33 +179,43 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bv, acc, 0, 0, 0);
           }
         }
-      }
-    }
-    if (wave_active) {
-      const int c = cp + wave * 32 + (lane & 31);
-      if (c < C) {
+        if ((s % nk) == nk - 1) {           // last key chunk of this panel: write the output block
+          const int c = cp + wave * 32 + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < N) out[((size_t)b * N + m) * C + c] = acc[r];
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < N && c < C) out[((size_t)b * N + m) * C + c] = acc[r];
+            acc[r] = 0.f;
+          }
         }
       }
+      if (NSTAGE == 1) __syncthreads();
+      if (more) store((NSTAGE == 2) ? (cur ^ 1) : 0);
+      __syncthreads();
     }
   }
 }
 
 int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st) {
   if (C & 3) { set_error("attention: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  if ((double)B * N * 3.0 * C >= 2147483647.0) { set_error("attention: qkv exceeds 2^31 elements"); return SR3_E_UNSUPPORTED; }
   const int Npad = (N + 31) & ~31;
-  const size_t stg = (size_t)((32 + 128) * AT_LDK > 32 * AT_LDV ? (32 + 128) * AT_LDK : 32 * AT_LDV);
-  const size_t smem = ((size_t)32 * (Npad + 4) + stg) * sizeof(float);
+  const size_t strip = (size_t)32 * (Npad + 4);
+  int nstage = 2;
+  size_t smem = (strip + 2 * (size_t)AT_STAGE) * sizeof(float);
+  if (smem > 160 * 1024) { nstage = 1; smem = (strip + (size_t)AT_STAGE) * sizeof(float); }
   if (smem > 160 * 1024) { set_error("attention: N=%d does not fit the LDS score strip", N); return SR3_E_UNSUPPORTED; }
-  static size_t attr_max = 0;
-  if (smem > attr_max) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_max = smem;
+  const int qblocks = (N + 31) / 32;
+  const int npan = (C + 127) / 128;
+  int zsplit = 1;
+  while (zsplit * 2 <= npan && (long)qblocks * B * zsplit < 256) zsplit *= 2;
+  static size_t attr_max[3] = {0, 0, 0};
+  auto kern = nstage == 2 ? k_attention<2> : k_attention<1>;
+  if (smem > attr_max[nstage]) {
+    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_max[nstage] = smem;
   }
-  hipLaunchKernelGGL(k_attention, dim3((N + 31) / 32, B), dim3(256), smem, st, qkv, N, C, out);
+  hipLaunchKernelGGL(kern, dim3(qblocks, B, zsplit), dim3(256), smem, st, qkv, N, C, out);
   SR3_LAUNCH_CHECK("k_attention");
   return SR3_OK;
 }

@@ -20,6 +20,8 @@
 // output for the next GroupNorm (double atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sr3_common.h"
 
 namespace sr3 {
@@ -27,7 +29,7 @@ namespace sr3 {
 __device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
 
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, bool X2>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   constexpr int LDK = 36, BK = 32;
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -54,10 +56,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   const int tb_i = bid / g.tiles_h;           // image-group index
   const int h0 = th_i * g.TH, w0 = tw_i * g.TW, b0 = tb_i * g.NB;
 
-  const int nchunks = (Cin + BK - 1) / BK;
-  const int cper = (nchunks + p.ksplit - 1) / p.ksplit;
+  // Segment 1 (the 3x3 conv): 32-channel chunks x 9 taps, split-K over chunks.  Segment 2 (X2: the
+  // fused 1x1 conv of x2, centre tap only) runs as a second, separate loop in the LAST split, so the
+  // main loop carries no per-segment selects.
+  const int Cin2 = X2 ? p.x2_C0 + p.x2_C1 : 0;
+  const int nch1 = (Cin + BK - 1) / BK;
+  const int nch2 = (Cin2 + BK - 1) / BK;
+  const int cper = (nch1 + p.ksplit - 1) / p.ksplit;
   const int c_begin = blockIdx.y * cper;
-  const int c_end = min(nchunks, c_begin + cper);
+  const int c_end = min(nch1, c_begin + cper);
+  const bool do_x2 = X2 && (int)blockIdx.y == p.ksplit - 1;
 
   // ---- halo items of this thread (fixed for the whole kernel) --------------------------------
   // item j covers halo pixel (tid >> 3) + 32 j, channel quad kq of the current chunk
@@ -86,20 +94,25 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   bool wok[BR];
   bool hvalid = false;      // channel quad of the staged chunk is inside Cin
 
-  auto load_halo = [&](int chunk) {
+  int cur_act = 0;          // prologue of the staged chunk (segment 2 has none)
+  auto load_halo = [&](auto seg2_tag, int chunk) {
+    constexpr bool seg2 = decltype(seg2_tag)::value;
+    const int CinS = seg2 ? Cin2 : Cin;
+    const int C0S = seg2 ? p.x2_C0 : p.C0;
     const int c = chunk * BK + kq * 4;
-    hvalid = c < Cin;
+    hvalid = c < CinS;
+    cur_act = seg2 ? 0 : p.act;
     const int ce = hvalid ? c : 0;
-    const bool second = ce >= p.C0;
-    const float* sp = second ? p.src1 : p.src0;
-    const int sC = second ? p.C1 : p.C0;
-    const int cs = second ? ce - p.C0 : ce;
+    const bool second = ce >= C0S;
+    const float* sp = seg2 ? (second ? p.x2_src1 : p.x2_src0) : (second ? p.src1 : p.src0);
+    const int sC = seg2 ? (second ? p.x2_C1 : p.x2_C0) : (second ? p.C1 : p.C0);
+    const int cs = second ? ce - C0S : ce;
 #pragma unroll
     for (int j = 0; j < HI; ++j) {
       const int off = hpix[j] >= 0 ? hpix[j] * sC + cs : 0;
       rh[j] = *reinterpret_cast<const f32x4*>(sp + off);
     }
-    if (p.act != 0) {
+    if (cur_act != 0) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int b = min(b0 + s, p.B - 1);
@@ -117,14 +130,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
       const int hp = lrow + 32 * j;
       if (hp < g.HP) {
         f32x4 v = rh[j];
-        if (p.act != 0) {
+        if (cur_act != 0) {
           const f32x4 sa = himg[j] ? ssa[1] : ssa[0];
           const f32x4 sb = himg[j] ? ssb[1] : ssb[0];
           v.x = fmaf(v.x, sa.x, sa.y);
           v.y = fmaf(v.y, sa.z, sa.w);
           v.z = fmaf(v.z, sb.x, sb.y);
           v.w = fmaf(v.w, sb.z, sb.w);
-          if (p.act == 2) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
+          if (cur_act == 2) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
         *reinterpret_cast<f32x4*>(&halo[hp * LDK + kq * 4]) = v;
@@ -132,16 +145,20 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
     }
   };
 
-  auto load_w = [&](int chunk, int tap) {
+  auto load_w = [&](auto seg2_tag, int chunk, int tap) {
+    constexpr bool seg2 = decltype(seg2_tag)::value;
+    const int CinS = seg2 ? Cin2 : Cin;
+    const float* wp = seg2 ? p.x2_w : p.w;
+    constexpr int ntap = seg2 ? 1 : 9;
     const int c = chunk * BK + kq * 4;
-    const bool cvalid = c < Cin;
+    const bool cvalid = c < CinS;
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const int n = tile_n * BN + lrow + 32 * j;
       const bool ok = cvalid && n < p.Cout;
       wok[j] = ok;
-      const int off = ok ? (n * 9 + tap) * Cin + c : 0;
-      rw[j] = *reinterpret_cast<const f32x4*>(p.w + off);
+      const int off = ok ? (n * ntap + tap) * CinS + c : 0;
+      rw[j] = *reinterpret_cast<const f32x4*>(wp + off);
     }
   };
   auto store_w = [&](int stage) {
@@ -174,9 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int stage, int tap) {
-    const int fr = tap / 3, fs = tap - fr * 3;
-    const int shift = fr * TWp + fs;
+  auto compute = [&](int stage, int shift) {
     const float* Bw = wst + stage * WSTAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -196,25 +211,51 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   };
 
   // ---- main loop: chunks (halo restage) x 9 taps (weight restage) ---------------------------------
+  using SEG1 = std::integral_constant<bool, false>;
+  using SEG2 = std::integral_constant<bool, true>;
   if (c_begin < c_end) {
-    load_halo(c_begin);
-    load_w(c_begin, 0);
+    load_halo(SEG1{}, c_begin);
+    load_w(SEG1{}, c_begin, 0);
     store_halo();
     store_w(0);
     __syncthreads();
     int stage = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool more_chunks = chunk + 1 < c_end;
-      if (more_chunks) load_halo(chunk + 1);        // in flight across the 9 taps of this chunk
+      if (more_chunks) load_halo(SEG1{}, chunk + 1);   // in flight across the 9 taps of this chunk
 #pragma unroll 1
       for (int tap = 0; tap < 9; ++tap) {
         const bool last_tap = tap == 8;
         const bool more = !last_tap || more_chunks;
-        if (more) load_w(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
-        if (!(p.dbg & 1)) compute(stage, tap);
+        if (more) load_w(SEG1{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+        const int fr = tap / 3, fs = tap - fr * 3;
+        if (!(p.dbg & 1)) compute(stage, fr * TWp + fs);
         if (more) store_w(stage ^ 1);
         if (last_tap && more_chunks) {
           __syncthreads();                          // every wave is done reading the halo tile
+          store_halo();
+        }
+        __syncthreads();
+        stage ^= 1;
+      }
+    }
+  }
+  if constexpr (X2) {
+    // ---- segment 2: 1x1 conv of x2, one k-step per chunk (halo centre, its own weights) ------------
+    if (do_x2 && nch2 > 0) {
+      load_halo(SEG2{}, 0);
+      load_w(SEG2{}, 0, 0);
+      store_halo();          // the last barrier of the main loop already retired every LDS read
+      store_w(0);
+      __syncthreads();
+      int stage = 0;
+      for (int chunk = 0; chunk < nch2; ++chunk) {
+        const bool more = chunk + 1 < nch2;
+        if (more) { load_halo(SEG2{}, chunk + 1); load_w(SEG2{}, chunk + 1, 0); }
+        compute(stage, TWp + 1);
+        if (more) {
+          store_w(stage ^ 1);
+          __syncthreads();
           store_halo();
         }
         __syncthreads();
@@ -228,6 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   __syncthreads();                                 // all MFMA reads of LDS are complete
   constexpr int LDT = 68;                          // 64 + 4 floats
   float* tr = smem + wave * (32 * LDT);
+  double* sred = reinterpret_cast<double*>(smem + 4 * 32 * LDT);   // [RB][BN][2] after the transpose regions
   const bool direct = p.ksplit == 1;
   const size_t Mtot = (size_t)p.B * H * W;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
@@ -236,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   const bool nok = n < p.Cout;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (X2 && direct && nok && p.x2_bias) bias4 += *reinterpret_cast<const f32x4*>(p.x2_bias + n);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -281,10 +324,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
         s1[k] += __shfl_xor(s1[k], 16); s1[k] += __shfl_xor(s1[k], 32);
         s2[k] += __shfl_xor(s2[k], 16); s2[k] += __shfl_xor(s2[k], 32);
       }
-      if (lane < 16 && nok && b < p.B) {
-        double* o = p.ostat + ((size_t)b * p.Cout + n) * 2;
+      if (lane < 16) {
+        // sred[row block][column of the tile][2]; row block = wave_m * 2 + i
+        double* o = sred + ((size_t)(wave_m * 2 + i) * BN + wave_n * 64 + c4 * 4) * 2;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { atomicAdd(o + 2 * k, s1[k]); atomicAdd(o + 2 * k + 1, s2[k]); }
+        for (int k = 0; k < 4; ++k) { o[2 * k] = s1[k]; o[2 * k + 1] = s2[k]; }
+      }
+    }
+  }
+  if (direct && p.ostat) {
+    // workgroup-level reduction of the row blocks that belong to one image, then ONE plain store
+    // per (image, tile, channel): partial statistics, summed later by the fold kernel.
+    __syncthreads();
+    constexpr int RB = WAVES_M * 2;                     // 32-row blocks in the tile
+    const int rb_per_img = RB / g.NB;
+    const int T = g.NB == 1 ? g.tiles_h * g.tiles_w : 1;
+    const int tix = g.NB == 1 ? th_i * g.tiles_w + tw_i : 0;
+    for (int idx = tid; idx < BN * g.NB; idx += 256) {
+      const int col = idx % BN, nb = idx / BN;
+      const int nn = tile_n * BN + col;
+      const int b = b0 + nb;
+      if (nn < p.Cout && b < p.B) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int r = 0; r < rb_per_img; ++r) {
+          const double* q = sred + ((size_t)(nb * rb_per_img + r) * BN + col) * 2;
+          a1 += q[0]; a2 += q[1];
+        }
+        double* o = p.ostat + (((size_t)b * T + tix) * p.Cout + nn) * 2;
+        o[0] = a1; o[1] = a2;
       }
     }
   }
@@ -294,15 +361,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
 namespace {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-template <int WAVES_M, int WAVES_N>
+template <int WAVES_M, int WAVES_N, bool X2>
 int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
   constexpr int smem_main = (HP_MAX * 36 + 2 * BN * 36) * 4;
-  constexpr int smem_epi = 4 * 32 * 68 * 4;
+  constexpr int smem_epi = 4 * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr_set = false;
-  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N>;
+  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2>;
   if (!attr_set) {
     SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -336,8 +403,11 @@ bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
   return g->HP <= (BM == 128 ? 200 : 324);
 }
 
+int halo_stats_slices(const HaloGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 1; }
+
 int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
-  return cfg == 6 ? launch_halo<4, 1>(p, g, st) : launch_halo<2, 2>(p, g, st);
+  if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true>(p, g, st) : launch_halo<2, 2, true>(p, g, st);
+  return cfg == 6 ? launch_halo<4, 1, false>(p, g, st) : launch_halo<2, 2, false>(p, g, st);
 }
 
 }  // namespace sr3

@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   // image, so the image index (FiLM row, statistics bucket) is wave-uniform per group.
   const bool direct = (p.ksplit == 1);
   const bool grp_uniform = (HoWo & 7) == 0;
-  const bool do_stat = direct && p.ostat != nullptr;   // host guarantees grp_uniform when set
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * M * p.Cout;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -203,25 +202,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     const bool nok = n < p.Cout;
     float bn = 0.f;
     if (direct && nok && p.bias) bn = p.bias[n];
-    double s1 = 0.0, s2 = 0.0;   // fused output statistics: column sums over this lane's rows
-    int sb = -1;
-    auto flush = [&]() {
-      if (sb >= 0) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lane < 32 && nok) {
-          atomicAdd(&p.ostat[((size_t)sb * p.Cout + n) * 2], s1);
-          atomicAdd(&p.ostat[((size_t)sb * p.Cout + n) * 2 + 1], s2);
-        }
-      }
-    };
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int mbase = tile_m * BM + wave_m * WM + 32 * i + 8 * g;   // wave-uniform
         const int bg = mbase / HoWo;
-        if (do_stat && mbase < M && bg != sb) { flush(); sb = bg; s1 = 0.0; s2 = 0.0; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int m = mbase + e + 4 * (lane >> 5);
@@ -233,14 +219,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
               if (p.film) v += p.film[(size_t)b * p.film_stride + n];
               if (p.res0)
                 v += (n < p.RC0) ? p.res0[(size_t)m * p.RC0 + n] : p.res1[(size_t)m * p.RC1 + (n - p.RC0)];
-              if (do_stat) { const double dv = (double)v; s1 += dv; s2 += dv * dv; }
             }
             dst[(size_t)m * p.Cout + n] = v;
           }
         }
       }
     }
-    if (do_stat) flush();
   }
 }
 
@@ -258,6 +242,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p) {
     for (int s = 0; s < p.ksplit; ++s)
       v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (p.x2_w && p.x2_bias) v += *reinterpret_cast<const f32x4*>(p.x2_bias + n);
     const int b = (int)(m / HoWo);
     if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
     if (p.res0) {
@@ -373,7 +358,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   conv_pick(p, tile_cfg, ksplit);
   p.ksplit = ksplit;
-  if (ksplit > 1 && p.ostat) { set_error("conv: fused output statistics are not available with split-K"); return SR3_E_UNSUPPORTED; }
+  if (p.ostat && (ksplit > 1 || tile_cfg < 5)) { set_error("conv: fused output statistics need the halo kernel without split-K"); return SR3_E_UNSUPPORTED; }
   { static const char* e = getenv("SR3_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (ksplit > 1) {
     const size_t need = (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout * sizeof(float);
@@ -382,6 +367,8 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   int rc;
   const bool k3 = p.ksize == 3;
+  if (p.x2_w && (tile_cfg < 5 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
+  if (p.x2_w && ((p.x2_C0 & 3) || (p.x2_C1 & 3) || !p.x2_src0 || (p.x2_C1 > 0 && !p.x2_src1))) { set_error("conv: bad x2 segment"); return SR3_E_BADARG; }
   if (tile_cfg >= 5) {
     HaloGeom g;
     if (tile_cfg > 6 || !halo_geometry(p, tile_cfg, &g)) { set_error("conv: halo tile_cfg %d does not fit this problem", tile_cfg); return SR3_E_UNSUPPORTED; }

@@ -42,7 +42,8 @@ struct Tensor {
   size_t off = 0;       // byte offset in the workspace
   size_t bytes = 0;
   int C = 0, H = 0, W = 0;
-  size_t stat_off = 0;  // byte offset of [B][C][2] doubles
+  size_t stat_off = 0;  // byte offset of the partial statistics [B][T][C][2] doubles (valid once stats_done)
+  int stat_T = 0;       // partials per image
   bool stats_done = false;
   bool valid = false;
 };
@@ -70,11 +71,11 @@ enum OpKind { OP_MEMSET, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_AT
 struct Op {
   OpKind kind;
   // generic offsets (bytes into workspace unless noted)
-  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
-  size_t p0 = 0, p1 = 0, p2 = 0;   // float offsets into the parameter arena
+  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, g = 0, h = 0;
+  size_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;   // float offsets into the parameter arena
   int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
   bool has_src1 = false, has_bias = false, has_film = false, has_res = false, has_res1 = false, has_ostat = false,
-       has_st1 = false;
+       has_st1 = false, has_x2 = false, has_x21 = false;
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
 };
@@ -97,7 +98,7 @@ struct sr3_plan {
   size_t fin_gn_w = 0, fin_gn_b = 0, fin_w = 0, fin_b = 0;
   int fin_cin = 0, out_ch = 0;
   // options
-  int fuse_stats = 0, tile_cfg = 0, ksplit = 0, keep_all = 0;
+  int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0;
   // compiled forward
   int built_batch = -1;
   int built_cond = -1;
@@ -366,8 +367,6 @@ struct Builder {
     t.C = C; t.H = H; t.W = W;
     t.bytes = (size_t)B * H * W * C * sizeof(float);
     t.off = act.alloc(t.bytes);
-    t.stat_off = stats_cursor;
-    stats_cursor += (size_t)B * C * 2 * sizeof(double);
     t.valid = true;
     T.push_back(t);
     return (int)T.size() - 1;
@@ -377,21 +376,28 @@ struct Builder {
     if (!P->keep_all) act.release(T[h].off, T[h].bytes);
     T[h].valid = false;
   }
+  void stat_slot(int h, int parts) {
+    Tensor& t = T[h];
+    t.stat_T = parts;
+    t.stat_off = stats_cursor;
+    stats_cursor += (size_t)B * parts * t.C * 2 * sizeof(double);
+    t.stats_done = true;
+  }
   void ensure_stats(int h) {
     Tensor& t = T[h];
     if (t.stats_done) return;
+    stat_slot(h, chan_stats_slices(B, t.H * t.W, t.C));
     Op o; o.kind = OP_STATS;
     o.a = t.off; o.b = t.stat_off; o.i0 = t.H * t.W; o.i1 = t.C;
     ops.push_back(o);
-    t.stats_done = true;
   }
   void fold(int x0, int x1, size_t gamma, size_t beta) {
     ensure_stats(x0);
     if (x1 >= 0) ensure_stats(x1);
     Op o; o.kind = OP_FOLD;
-    o.a = T[x0].stat_off; o.i0 = T[x0].C;
+    o.a = T[x0].stat_off; o.i0 = T[x0].C; o.i3 = T[x0].stat_T;
     o.has_st1 = x1 >= 0;
-    if (x1 >= 0) { o.b = T[x1].stat_off; o.i1 = T[x1].C; }
+    if (x1 >= 0) { o.b = T[x1].stat_off; o.i1 = T[x1].C; o.i4 = T[x1].stat_T; }
     o.i2 = T[x0].H * T[x0].W;
     o.p0 = gamma; o.p1 = beta;
     ops.push_back(o);
@@ -399,7 +405,8 @@ struct Builder {
   }
   // generic conv over the virtual concat (x0|x1); residual is the concat view (r0|r1)
   int conv(int x0, int x1, int Cout, int ksize, int stride, int ups, int act_mode, size_t w, bool has_bias,
-           size_t bias, int film_row, int r0, int r1, bool want_stats) {
+           size_t bias, int film_row, int r0, int r1, bool want_stats, int q0 = -1, int q1 = -1, size_t qw = 0,
+           size_t qb = 0) {
     const int C0 = T[x0].C, C1 = x1 >= 0 ? T[x1].C : 0;
     const int Hi = T[x0].H << ups, Wi = T[x0].W << ups;
     const int pad = ksize / 2;
@@ -422,22 +429,44 @@ struct Builder {
     o.e = T[out].off;
     o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
     conv_pick(c, o.tile_cfg, o.ksplit);
+    if (q0 >= 0) {   // fused 1x1 segment (res_conv); caller checked can_fuse_x2()
+      c.x2_C0 = T[q0].C; c.x2_C1 = q1 >= 0 ? T[q1].C : 0;
+      o.has_x2 = true; o.g = T[q0].off; o.has_x21 = q1 >= 0; if (q1 >= 0) o.h = T[q1].off;
+      o.p2 = qw; o.p3 = qb;
+      flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(c.x2_C0 + c.x2_C1);
+    }
     if (o.ksplit > 1) max_scratch = std::max(max_scratch, (size_t)o.ksplit * B * Ho * Wo * Cout * sizeof(float));
     // split-K convs leave the statistics to the (cheap, small-tensor) stand-alone pass
-    if (want_stats && P->fuse_stats && o.ksplit == 1 && ((Ho * Wo) & 7) == 0) {
-      o.has_ostat = true; o.f = T[out].stat_off;
-      T[out].stats_done = true;
+    if (want_stats && P->fuse_stats && o.ksplit == 1 && o.tile_cfg >= 5) {
+      HaloGeom hg;
+      if (halo_geometry(c, o.tile_cfg, &hg)) {
+        stat_slot(out, halo_stats_slices(hg));
+        o.has_ostat = true; o.f = T[out].stat_off;
+      }
     }
     ops.push_back(o);
     flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(C0 + C1) * ksize * ksize;
     return out;
+  }
+  // can block2's conv run on the halo kernel (which can take res_conv as a second K-segment)?
+  bool can_fuse_x2(int h1, int Cout) {
+    if (!P->fuse_res) return false;
+    ConvParams c;
+    memset(&c, 0, sizeof(c));
+    c.C0 = T[h1].C; c.B = B; c.Hs = T[h1].H; c.Ws = T[h1].W; c.stride = 1; c.ksize = 3;
+    c.Ho = T[h1].H; c.Wo = T[h1].W; c.Cout = Cout;
+    int cfg = P->tile_cfg, ks = P->ksplit;
+    conv_pick(c, cfg, ks);
+    return cfg >= 5;
   }
   int res_block(int x0, int x1, const ResLayer& R) {
     fold(x0, x1, R.gn1_w, R.gn1_b);
     const int h1 = conv(x0, x1, R.cout, 3, 1, 0, 2, R.c1_w, true, R.c1_b, R.film_off, -1, -1, true);
     fold(h1, -1, R.gn2_w, R.gn2_b);
     int out;
-    if (R.has_rc) {
+    if (R.has_rc && can_fuse_x2(h1, R.cout)) {
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, -1, -1, true, x0, x1, R.rc_w, R.rc_b);
+    } else if (R.has_rc) {
       const int r = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
       out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, r, -1, true);
       drop(r);
@@ -474,7 +503,6 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
   std::vector<Op>& ops = P->ops;
   const int S = d.image_size, inner = d.inner_channel;
 
-  { Op o; o.kind = OP_MEMSET; ops.push_back(o); }
   { Op o; o.kind = OP_EMBED; ops.push_back(o); }
   bld.flops += 2.0 * B * (2.0 * 4 * inner * inner + (double)P->F * inner);
 
@@ -560,7 +588,6 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
     ++op_index;
     switch (o.kind) {
       case OP_MEMSET:
-        if (P->stats_bytes) SR3_HIP(hipMemsetAsync(ws + P->stats_off, 0, P->stats_bytes, st));
         break;
       case OP_EMBED: {
         EmbedParams e;
@@ -588,9 +615,10 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
                         reinterpret_cast<double*>(ws + P->stats_off + o.b), st);
         break;
       case OP_FOLD:
-        rc = gn_finalize(reinterpret_cast<const double*>(ws + P->stats_off + o.a), o.i0,
+        rc = gn_finalize(reinterpret_cast<const double*>(ws + P->stats_off + o.a), o.i0, o.i3,
                          o.has_st1 ? reinterpret_cast<const double*>(ws + P->stats_off + o.b) : nullptr,
-                         o.has_st1 ? o.i1 : 0, B, o.i2, d.norm_groups, params + o.p0, params + o.p1, 1e-5f, ss, st);
+                         o.has_st1 ? o.i1 : 0, o.has_st1 ? o.i4 : 0, B, o.i2, d.norm_groups, params + o.p0,
+                         params + o.p1, 1e-5f, ss, st);
         last_hw = o.i2;
         break;
       case OP_CONV: {
@@ -605,6 +633,12 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
         c.res1 = o.has_res1 ? reinterpret_cast<const float*>(ws + o.d) : nullptr;
         c.out = reinterpret_cast<float*>(ws + o.e);
         c.ostat = o.has_ostat ? reinterpret_cast<double*>(ws + P->stats_off + o.f) : nullptr;
+        if (o.has_x2) {
+          c.x2_src0 = reinterpret_cast<const float*>(ws + o.g);
+          c.x2_src1 = o.has_x21 ? reinterpret_cast<const float*>(ws + o.h) : nullptr;
+          c.x2_w = params + o.p2;
+          c.x2_bias = params + o.p3;
+        }
         rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + P->scratch_off), P->scratch_bytes, st);
         break;
       }
@@ -671,6 +705,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "tile_cfg")) slot = &plan->tile_cfg;
   else if (!strcmp(key, "ksplit")) slot = &plan->ksplit;
   else if (!strcmp(key, "keep_all")) slot = &plan->keep_all;
+  else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
   *slot = value;
@@ -789,7 +824,21 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
   c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
-  if (out_stats && ((c.Ho * c.Wo) & 7)) { set_error("fused stats need Ho*Wo %% 8 == 0"); return SR3_E_UNSUPPORTED; }
+  return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
+}
+int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int H, int W, int Cout,
+                       const float* w, const float* bias, const float* ss, int act, const float* film, int film_stride,
+                       const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1, const float* x2_w,
+                       const float* x2_bias, float* out, double* out_stats, int tile_cfg, int ksplit, void* scratch,
+                       size_t scratch_bytes, void* stream) {
+  if (!src0 || !w || !out || !x2_src0 || !x2_w) { set_error("null argument"); return SR3_E_BADARG; }
+  ConvParams c;
+  memset(&c, 0, sizeof(c));
+  c.src0 = src0; c.src1 = src1; c.C0 = C0; c.C1 = src1 ? C1 : 0;
+  c.B = B; c.Hs = H; c.Ws = W; c.stride = 1; c.ksize = 3; c.Ho = H; c.Wo = W;
+  c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
+  c.out = out; c.ostat = out_stats; c.ksplit = 1;
+  c.x2_src0 = x2_src0; c.x2_src1 = x2_src1; c.x2_C0 = x2_C0; c.x2_C1 = x2_src1 ? x2_C1 : 0; c.x2_w = x2_w; c.x2_bias = x2_bias;
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
 }
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit) {
@@ -802,10 +851,23 @@ int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, 
   if (!x || !stat) { set_error("null argument"); return SR3_E_BADARG; }
   return chan_stats(x, B, HW, C, stat, static_cast<hipStream_t>(stream));
 }
-int sr3_groupnorm_fold_f32(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
-                           const float* gamma, const float* beta, float eps, float* ss, void* stream) {
+int sr3_groupnorm_stats_slices(int B, int HW, int C) { return chan_stats_slices(B, HW, C); }
+int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cout, int tile_cfg) {
+  ConvParams c;
+  memset(&c, 0, sizeof(c));
+  c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = 1; c.ksize = 3; c.Ho = Hs << ups; c.Wo = Ws << ups;
+  c.Cout = Cout; c.C0 = 32;
+  int ks = 1;
+  conv_pick(c, tile_cfg, ks);
+  HaloGeom g;
+  if (tile_cfg < 5 || !halo_geometry(c, tile_cfg, &g)) return 0;
+  return halo_stats_slices(g);
+}
+int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW,
+                           int groups, const float* gamma, const float* beta, float eps, float* ss, void* stream) {
   if (!stat0 || !gamma || !beta || !ss) { set_error("null argument"); return SR3_E_BADARG; }
-  return gn_finalize(stat0, C0, stat1, stat1 ? C1 : 0, B, HW, groups, gamma, beta, eps, ss, static_cast<hipStream_t>(stream));
+  return gn_finalize(stat0, C0, T0, stat1, stat1 ? C1 : 0, stat1 ? T1 : 0, B, HW, groups, gamma, beta, eps, ss,
+                     static_cast<hipStream_t>(stream));
 }
 int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream) {
   if (!qkv || !out) { set_error("null argument"); return SR3_E_BADARG; }

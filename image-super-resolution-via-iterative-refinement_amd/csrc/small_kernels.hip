@@ -13,10 +13,13 @@ __device__ __forceinline__ float add_rn(float a, float b) { float r = a + b; asm
 __device__ __forceinline__ float sub_rn(float a, float b) { float r = a - b; asm volatile("" : "+v"(r)); return r; }
 
 // ---------------------------------------------------------------------------------------------
-// per-(image, channel) sum / sum-of-squares in double.  x: NHWC [B][HW][C].
-// Feeds nn.GroupNorm (model/sr3_modules/unet.py:84,119): keeping *channel* sums lets one pass
-// serve any grouping, including groups that straddle a skip-concat seam (unet.py:255).
-// grid (slices, cblocks, B); LQ lanes across channel quads, 256/LQ lanes across pixels.
+// GroupNorm statistics (nn.GroupNorm, model/sr3_modules/unet.py:84,119) as PARTIAL per-(image,
+// channel) {sum, sumsq} in double:  stat[b][t][c][2], t < T partials per image.  Producers write
+// disjoint partials with plain stores (this kernel: one per pixel slice; the halo conv: one per
+// spatial tile) and the fold kernel sums them in a fixed order -- no atomics, no memset, bitwise
+// reproducible.  Keeping *channel* sums lets one pass serve any grouping, including groups that
+// straddle a skip-concat seam (unet.py:255).
+// x: NHWC [B][HW][C].  grid (T slices, cblocks, B); LQ lanes across channel quads, 256/LQ across pixels.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x, int HW, int C, int LQ,
                                                      int pix_per_block, double* __restrict__ stat) {
@@ -26,6 +29,7 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
   const int ql = tid % LQ, pl = tid / LQ, PP = 256 / LQ;
   const int q = blockIdx.y * LQ + ql;
   const int b = blockIdx.z;
+  const int T = gridDim.x;
   const int p0 = blockIdx.x * pix_per_block;
   const int p1 = min(HW, p0 + pix_per_block);
   double s[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -45,14 +49,13 @@ __global__ __launch_bounds__(256) void k_chan_stats(const float* __restrict__ x,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { s[e] += red[(k * LQ + ql) * 8 + e]; s2[e] += red[(k * LQ + ql) * 8 + 4 + e]; }
     }
-    double* o = stat + ((size_t)b * C + q * 4) * 2;
+    double* o = stat + (((size_t)b * T + blockIdx.x) * C + q * 4) * 2;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { atomicAdd(o + 2 * e, s[e]); atomicAdd(o + 2 * e + 1, s2[e]); }
+    for (int e = 0; e < 4; ++e) { o[2 * e] = s[e]; o[2 * e + 1] = s2[e]; }
   }
 }
 
-int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st) {
-  if (C & 3) { set_error("chan_stats: C %% 4 != 0 (%d)", C); return SR3_E_UNSUPPORTED; }
+static void chan_stats_geometry(int B, int HW, int C, int* LQ_, int* cblocks_, int* ppb_, int* slices_) {
   const int nq = C >> 2;
   int LQ = 1;
   while (LQ < nq && LQ < 64) LQ <<= 1;
@@ -61,52 +64,75 @@ int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t s
   long base_blocks = (long)cblocks * B;
   long want = 2048 / (base_blocks > 0 ? base_blocks : 1);
   if (want < 1) want = 1;
+  if (want > 64) want = 64;
   long max_slices = (HW + PP - 1) / PP;
   if (want > max_slices) want = max_slices;
   int ppb = (int)((HW + want - 1) / want);
   ppb = ((ppb + PP - 1) / PP) * PP;
-  const int slices = (HW + ppb - 1) / ppb;
+  *LQ_ = LQ; *cblocks_ = cblocks; *ppb_ = ppb; *slices_ = (HW + ppb - 1) / ppb;
+}
+
+int chan_stats_slices(int B, int HW, int C) {
+  int LQ, cb, ppb, sl;
+  chan_stats_geometry(B, HW, C, &LQ, &cb, &ppb, &sl);
+  return sl;
+}
+
+int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st) {
+  if (C & 3) { set_error("chan_stats: C %% 4 != 0 (%d)", C); return SR3_E_UNSUPPORTED; }
+  int LQ, cblocks, ppb, slices;
+  chan_stats_geometry(B, HW, C, &LQ, &cblocks, &ppb, &slices);
   hipLaunchKernelGGL(k_chan_stats, dim3(slices, cblocks, B), dim3(256), 0, st, x, HW, C, LQ, ppb, stat);
   SR3_LAUNCH_CHECK("k_chan_stats");
   return SR3_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// GroupNorm fold: scale = rstd * gamma, shift = beta - mean * scale per (image, channel) of the
-// virtual concat [src0 | src1].  Biased variance, eps inside the sqrt (torch GroupNorm).
+// GroupNorm fold: one wave per (image, group) sums the partials of the group's channels over the
+// virtual concat [src0 | src1] in a fixed order, then writes scale = rstd * gamma and
+// shift = beta - mean * scale per channel.  Biased variance, eps inside the sqrt (torch GroupNorm).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gn_finalize(const double* __restrict__ st0, int C0,
-                                                      const double* __restrict__ st1, int C1, int B, int HW,
-                                                      int groups, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps,
-                                                      float* __restrict__ ss) {
+__global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ st0, int C0, int T0,
+                                                     const double* __restrict__ st1, int C1, int T1, int HW,
+                                                     int groups, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     float* __restrict__ ss) {
   const int C = C0 + C1;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * C) return;
-  const int b = idx / C, c = idx - b * C;
+  const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int cpg = C / groups;
-  const int g0 = (c / cpg) * cpg;
+  const int lane = threadIdx.x;
   double s = 0.0, s2 = 0.0;
-  for (int k = g0; k < g0 + cpg; ++k) {
-    const double* q = (k < C0) ? st0 + ((size_t)b * C0 + k) * 2 : st1 + ((size_t)b * C1 + (k - C0)) * 2;
-    s += q[0]; s2 += q[1];
+  for (int k = 0; k < cpg; ++k) {
+    const int c = g * cpg + k;
+    const bool second = c >= C0;
+    const double* base = second ? st1 : st0;
+    const int Cs = second ? C1 : C0, Ts = second ? T1 : T0, cs = second ? c - C0 : c;
+    for (int t = lane; t < Ts; t += 64) {
+      const double* q = base + (((size_t)b * Ts + t) * Cs + cs) * 2;
+      s += q[0]; s2 += q[1];
+    }
   }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }
   const double cnt = (double)HW * cpg;
   const double mean = s / cnt;
   double var = s2 / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = rstd * gamma[c];
-  ss[(size_t)idx * 2] = sc;
-  ss[(size_t)idx * 2 + 1] = beta[c] - (float)mean * sc;
+  for (int k = lane; k < cpg; k += 64) {
+    const int c = g * cpg + k;
+    const float sc = rstd * gamma[c];
+    float* o = ss + ((size_t)b * C + c) * 2;
+    o[0] = sc;
+    o[1] = beta[c] - (float)mean * sc;
+  }
 }
 
-int gn_finalize(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW, int groups,
                 const float* gamma, const float* beta, float eps, float* ss, hipStream_t st) {
   const int C = C0 + C1;
   if (groups <= 0 || C % groups) { set_error("gn_finalize: C=%d not divisible by groups=%d", C, groups); return SR3_E_BADARG; }
-  const int n = B * C;
-  hipLaunchKernelGGL(k_gn_finalize, dim3((n + 255) / 256), dim3(256), 0, st, stat0, C0, stat1, C1, B, HW, groups,
+  hipLaunchKernelGGL(k_gn_finalize, dim3(B * groups), dim3(64), 0, st, stat0, C0, T0, stat1, C1, T1, HW, groups,
                      gamma, beta, eps, ss);
   SR3_LAUNCH_CHECK("k_gn_finalize");
   return SR3_OK;

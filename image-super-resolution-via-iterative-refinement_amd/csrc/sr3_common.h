@@ -54,8 +54,16 @@ struct ConvParams {
   float* out;          // [B,Ho,Wo,Cout]
   float* partial;      // split-K scratch [ksplit][M][Cout] (ksplit > 1)
   int ksplit;
-  double* ostat;       // optional: per-(b, n) {sum, sumsq} accumulators of the OUTPUT (fused GN stats)
+  double* ostat;       // optional (halo kernel only): partial {sum, sumsq} of the OUTPUT, [B][T][Cout][2]
   int dbg;             // profiling ablations only (env SR3_CONV_DBG): 1 = skip MFMA, 2 = skip staging
+  // Optional second K-segment (halo kernel only): a 1x1 conv of another tensor (virtual concat
+  // x2_src0|x2_src1, same spatial size as the output, no prologue) accumulated into the same
+  // output tile -- ResnetBlock's `res_conv(x)` (unet.py:102-103,110) folded into block2's conv.
+  const float* x2_src0;
+  const float* x2_src1;
+  int x2_C0, x2_C1;
+  const float* x2_w;    // [Cout][x2_C0 + x2_C1]
+  const float* x2_bias; // [Cout] or null
 };
 
 // tile_cfg: 0 = auto; im2col-staged implicit GEMM: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128;
@@ -75,11 +83,15 @@ bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g);
 int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
-// per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]; stat must be zeroed.
+// partial per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]:
+// stat[B][T][C][2] with T = chan_stats_slices(B, HW, C); plain stores, no memset needed.
+int chan_stats_slices(int B, int HW, int C);
 int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st);
-// GroupNorm fold: (chanstat of up to two concat sources) + gamma/beta -> ss[B][C0+C1][2]
-int gn_finalize(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
+// GroupNorm fold: partial stats of up to two concat sources + gamma/beta -> ss[B][C0+C1][2]
+int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW, int groups,
                 const float* gamma, const float* beta, float eps, float* ss, hipStream_t st);
+// partials per image the halo conv writes into ConvParams::ostat for this geometry
+int halo_stats_slices(const HaloGeom& g);
 // first conv of the UNet: NCHW inputs (virtual concat of a: Ca, b: Cb channels), 3x3 pad 1,
 // weights OHWI [Cout][9][Ca+Cb], output NHWC [B,H,W,Cout]
 int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,

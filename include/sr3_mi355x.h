@@ -77,7 +77,7 @@ size_t sr3_plan_param_floats(const sr3_plan* plan);
 int sr3_plan_num_ops(sr3_plan* plan, int batch);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
-/* tuning knobs: key in {"fuse_stats", "tile_cfg", "ksplit", "keep_all"}; returns previous value */
+/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all"}; returns previous value */
 int sr3_plan_set_option(sr3_plan* plan, const char* key, int value);
 
 /* Debug taps: where each top-level layer output (downs.i / mid.i / ups.i, NHWC) lives inside the
@@ -146,13 +146,25 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
                  int act, const float* film, int film_stride, const float* res0, int RC0, const float* res1,
                  int RC1, float* out, double* out_stats, int tile_cfg, int ksplit, void* scratch,
                  size_t scratch_bytes, void* stream);
+/* ResnetBlock tail in one launch (unet.py:105-110): out = conv3x3(act(src0|src1)) + bias + film
+ *   + conv1x1(x2_src0|x2_src1; x2_w [Cout][x2_C0+x2_C1]) + x2_bias  -- block2's conv with `res_conv(x)`
+ * accumulated as a second K-segment of the same output tile (halo kernel: tile_cfg 0 | 5 | 6). */
+int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int H, int W, int Cout,
+                       const float* w_ohwi, const float* bias, const float* ss, int act, const float* film,
+                       int film_stride, const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1,
+                       const float* x2_w, const float* x2_bias, float* out, double* out_stats, int tile_cfg,
+                       int ksplit, void* scratch, size_t scratch_bytes, void* stream);
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit);
-/* nn.GroupNorm statistics (unet.py:84,119): per-(image, channel) {sum, sumsq} in double of an NHWC
- * tensor; `stat` ([B][C][2] doubles) must be zero on entry. */
+/* nn.GroupNorm statistics (unet.py:84,119) as PARTIAL per-(image, channel) {sum, sumsq} in double of
+ * an NHWC tensor: stat[B][T][C][2] with T = sr3_groupnorm_stats_slices(B, HW, C).  Plain stores (no
+ * atomics, no zeroing needed); summed in a fixed order by the fold => bitwise reproducible. */
+int sr3_groupnorm_stats_slices(int B, int HW, int C);
 int sr3_groupnorm_stats_f32(const float* x_nhwc, int B, int HW, int C, double* stat, void* stream);
-/* fold statistics of the concat (stat0|stat1) with gamma/beta into ss[B][C0+C1][2] */
-int sr3_groupnorm_fold_f32(const double* stat0, int C0, const double* stat1, int C1, int B, int HW, int groups,
-                           const float* gamma, const float* beta, float eps, float* ss, void* stream);
+/* T of the partial statistics sr3_conv_f32 writes into out_stats (0: this geometry cannot fuse them) */
+int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cout, int tile_cfg);
+/* fold partial statistics of the concat (stat0|stat1) with gamma/beta into ss[B][C0+C1][2] */
+int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW,
+                           int groups, const float* gamma, const float* beta, float eps, float* ss, void* stream);
 /* SelfAttention core (unet.py:127-139): qkv NHWC [B][N][3C] -> out [B][N][C] */
 int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream);
 /* noise-level / timestep embedding + MLP + all FiLM rows (unet.py:18-50,179-184): see sr3_common.h */

@@ -47,7 +47,10 @@ def conv_call(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, re
     r0 = None if res0 is None else g(nhwc(res0))
     r1 = None if res1 is None else g(nhwc(res1))
     out = torch.full((B, Ho, Wo, Cout), float('nan'), device=d)
-    stats = torch.zeros(B, Cout, 2, dtype=torch.float64, device=d) if want_stats else None
+    stats = None
+    if want_stats:
+        Tst = int(lib.sr3_conv_stats_slices(B, Hs, Ws, ups, Cout, tile_cfg))
+        stats = torch.full((B, max(Tst, 1), Cout, 2), float('nan'), dtype=torch.float64, device=d)
     nb = int(lib.sr3_conv_scratch_bytes(B, Ho, Wo, Cin, Cout, k, tile_cfg, ksplit))
     scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
     L.check(lib.sr3_conv_f32(L.ptr(s0), C0, L.ptr(s1), C1, B, Hs, Ws, ups, stride, k, Cout, L.ptr(wd), L.ptr(bd),
@@ -55,7 +58,7 @@ def conv_call(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, re
                              0 if res0 is None else res0.shape[1], L.ptr(r1), 0 if res1 is None else res1.shape[1],
                              L.ptr(out), L.ptr(stats), tile_cfg, ksplit, L.ptr(scratch), nb, stream()))
     torch.cuda.synchronize()
-    return nchw(out).cpu(), (None if stats is None else stats.cpu())
+    return nchw(out).cpu(), (None if stats is None else stats.cpu().sum(1))
 
 
 def conv_ref(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, res1=None, ups=0, stride=1):

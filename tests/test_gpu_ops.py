@@ -83,11 +83,16 @@ def test_conv(case, tile_cfg, ksplit):
 
 
 @pytest.mark.parametrize('ksplit', [1, 2])
-@pytest.mark.parametrize('tile_cfg', [0, 3, 5])
-def test_conv_fused_output_stats(ksplit, tile_cfg):
-    case = ('stats', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True)
+@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6])
+@pytest.mark.parametrize('case', [('stats8', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True),
+                                  ('stats32', 2, 32, 32, 32, 32, 160, 3, 1, 0, 2, True, True, True),
+                                  ('stats_up', 2, 32, 0, 16, 16, 64, 3, 1, 1, 0, False, False, True)],
+                         ids=['8x8', '32x32', 'up32'])
+def test_conv_fused_output_stats(ksplit, tile_cfg, case):
     src0, src1, w, kw = _make_case(case)
-    if ksplit > 1:      # split-K convs leave the statistics to the stand-alone pass
+    lib = L.load()
+    fits = lib.sr3_conv_stats_slices(src0.shape[0], src0.shape[2], src0.shape[3], kw['ups'], w.shape[0], tile_cfg) > 0
+    if ksplit > 1 or not fits:      # only the halo kernel without split-K fuses the statistics
         with pytest.raises(L.Sr3Error):
             G.conv_call(src0, src1, w, ksplit=ksplit, tile_cfg=tile_cfg, want_stats=True, **kw)
         return
@@ -100,27 +105,71 @@ def test_conv_fused_output_stats(ksplit, tile_cfg):
     assert torch.allclose(st[:, :, 1], s2, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (5, 1), (6, 1), (5, 2), (6, 3)])
+@pytest.mark.parametrize('shape', [(2, 64, 0, 16, 16, 128, 96, 32), (3, 32, 0, 8, 8, 64, 24, 8), (1, 128, 0, 32, 32, 64, 192, 0)],
+                         ids=['16x16', '8x8_oddB', '32x32'])
+def test_block_conv_with_fused_res_conv(shape, tile_cfg, ksplit):
+    """block2 conv3x3 + res_conv 1x1 of the (concat) block input in one launch."""
+    import torch.nn.functional as F
+    B, C0, C1, H, W, Cout, X0, X1 = shape
+    lib = L.load()
+    d = G.dev()
+    case = ('blk', B, C0, C1, H, W, Cout, 3, 1, 0, 2, True, False, True)
+    src0, src1, w, kw = _make_case(case)
+    x2a = _rand(B, X0, H, W, seed=21)
+    x2b = _rand(B, X1, H, W, seed=22) if X1 else None
+    w2 = _rand(Cout, X0 + X1, 1, 1, seed=23) * 0.1
+    b2 = _rand(Cout, seed=24)
+    ref = G.conv_ref(src0, src1, w, **kw) + F.conv2d((x2a if x2b is None else torch.cat([x2a, x2b], 1)).double(),
+                                                     w2.double(), b2.double())
+    g = lambda t: None if t is None else t.to(d)
+    dv = dict(s0=g(G.nhwc(src0)), w=g(G.ohwi(w)), bias=g(kw['bias']), ss=g(kw['ss']), film=g(kw['film']),
+              x2a=g(G.nhwc(x2a)), x2b=None if x2b is None else g(G.nhwc(x2b)), w2=g(w2.reshape(Cout, -1).contiguous()),
+              b2=g(b2))
+    out = torch.full((B, H, W, Cout), float('nan'), device=d)
+    nb = int(lib.sr3_conv_scratch_bytes(B, H, W, C0, Cout, 3, tile_cfg, ksplit))
+    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
+    rc = lib.sr3_block_conv_f32(L.ptr(dv['s0']), C0, None, 0, B, H, W, Cout, L.ptr(dv['w']), L.ptr(dv['bias']),
+                                L.ptr(dv['ss']), 2, L.ptr(dv['film']), Cout, L.ptr(dv['x2a']), X0, L.ptr(dv['x2b']), X1,
+                                L.ptr(dv['w2']), L.ptr(dv['b2']), L.ptr(out), None, tile_cfg, ksplit, L.ptr(scratch),
+                                nb, G.stream())
+    torch.cuda.synchronize()
+    if rc != 0:
+        msg = lib.sr3_last_error().decode()
+        if 'does not fit' in msg or 'empty split' in msg:
+            pytest.skip(msg)
+        L.check(rc)
+    G.assert_close(G.nchw(out).cpu(), ref, what='block conv + res_conv')
+
+
 @pytest.mark.parametrize('B,HW,C', [(2, 256, 64), (3, 100, 24), (2, 16384, 64), (4, 64, 512), (1, 16, 1024)])
 def test_groupnorm_stats_and_fold(B, HW, C):
     lib = L.load()
     d = G.dev()
     x = _rand(B, HW, C, seed=3) * 2 + 0.5
     xd = x.to(d)
-    st = torch.zeros(B, C, 2, dtype=torch.float64, device=d)
+    T = int(lib.sr3_groupnorm_stats_slices(B, HW, C))
+    st = torch.full((B, T, C, 2), float('nan'), dtype=torch.float64, device=d)     # no zeroing required
     L.check(lib.sr3_groupnorm_stats_f32(L.ptr(xd), B, HW, C, L.ptr(st), G.stream()))
     torch.cuda.synchronize()
-    assert torch.allclose(st[:, :, 0].cpu(), x.double().sum(1), rtol=1e-12, atol=1e-9)
-    assert torch.allclose(st[:, :, 1].cpu(), (x.double() ** 2).sum(1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(st[..., 0].sum(1).cpu(), x.double().sum(1), rtol=1e-12, atol=1e-9)
+    assert torch.allclose(st[..., 1].sum(1).cpu(), (x.double() ** 2).sum(1), rtol=1e-12, atol=1e-9)
     # fold as a concat of two halves with groups straddling the seam where possible
     C0 = C // 2 - 4 if C >= 16 else C
     C1 = C - C0
     groups = 4 if C % 4 == 0 else 1
     gamma, beta = _rand(C, seed=4) * 0.2 + 1, _rand(C, seed=5) * 0.2
-    st0 = st[:, :C0].contiguous()
-    st1 = st[:, C0:].contiguous() if C1 else None
+    st0 = st[:, :, :C0].contiguous()
+    # second source with a different number of partials (as a tensor from another producer would have)
+    st1 = None
+    T1 = 0
+    if C1:
+        half = st[:, :, C0:] * 0.5
+        st1 = torch.cat([half, half], dim=1).contiguous()
+        T1 = 2 * T
     ss = torch.empty(B, C, 2, device=d)
     gd, bd = gamma.to(d), beta.to(d)          # keep device copies alive across the async call
-    L.check(lib.sr3_groupnorm_fold_f32(L.ptr(st0), C0, L.ptr(st1), C1, B, HW, groups, L.ptr(gd),
+    L.check(lib.sr3_groupnorm_fold_f32(L.ptr(st0), C0, T, L.ptr(st1), C1, T1, B, HW, groups, L.ptr(gd),
                                        L.ptr(bd), 1e-5, L.ptr(ss), G.stream()))
     torch.cuda.synchronize()
     xn = x.permute(0, 2, 1).reshape(B, C, HW, 1)
