@@ -228,28 +228,62 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   }
 }
 
-// ---- split-K reduction + epilogue -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p) {
+// ---- split-K reduction + epilogue (+ optional partial GroupNorm statistics of the output) -------
+// A block owns `rpb` consecutive output rows (pixels) -- inside one image when statistics are
+// requested -- lanes run along channel quads (coalesced 16-byte accesses), the 4 waves along rows.
+__global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int rpb) {
+  __shared__ double red[4 * 64 * 8];
   const int HoWo = p.Ho * p.Wo;
   const size_t M = (size_t)p.B * HoWo;
   const int nq = p.Cout >> 2;
-  const size_t total = M * nq;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = idx / nq;
-    const int n = (int)(idx - m * nq) * 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < p.ksplit; ++s)
-      v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if (p.x2_w && p.x2_bias) v += *reinterpret_cast<const f32x4*>(p.x2_bias + n);
-    const int b = (int)(m / HoWo);
-    if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
-    if (p.res0) {
-      if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + m * p.RC0 + n);
-      else v += *reinterpret_cast<const f32x4*>(p.res1 + m * p.RC1 + (n - p.RC0));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)blockIdx.x * rpb;
+  for (int q0 = 0; q0 < nq; q0 += 64) {
+    const int q = q0 + lane;
+    const int n = q * 4;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (q < nq) {
+      f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) cb += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.x2_w && p.x2_bias) cb += *reinterpret_cast<const f32x4*>(p.x2_bias + n);
+      for (int r = wave; r < rpb; r += 4) {
+        const size_t m = row0 + r;
+        if (m >= M) break;
+        f32x4 v = cb;
+        for (int s = 0; s < p.ksplit; ++s)
+          v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+        const int b = (int)(m / HoWo);
+        if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
+        if (p.res0) {
+          if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + m * p.RC0 + n);
+          else v += *reinterpret_cast<const f32x4*>(p.res1 + m * p.RC1 + (n - p.RC0));
+        }
+        *reinterpret_cast<f32x4*>(p.out + m * p.Cout + n) = v;
+        if (p.ostat) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const double dv = (double)v[e]; s1[e] += dv; s2[e] += dv * dv; }
+        }
+      }
     }
-    *reinterpret_cast<f32x4*>(p.out + m * p.Cout + n) = v;
+    if (p.ostat) {      // uniform branch: fixed-order reduction over the 4 row lanes, one plain store
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { red[(wave * 64 + lane) * 8 + e] = s1[e]; red[(wave * 64 + lane) * 8 + 4 + e] = s2[e]; }
+      __syncthreads();
+      if (wave == 0 && q < nq && row0 < M) {
+        const int b = (int)(row0 / HoWo);
+        const int T = HoWo / rpb;
+        const int slice = (int)(row0 - (size_t)b * HoWo) / rpb;
+        double* o = p.ostat + (((size_t)b * T + slice) * p.Cout + n) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) { a1 += red[(w * 64 + lane) * 8 + e]; a2 += red[(w * 64 + lane) * 8 + 4 + e]; }
+          o[2 * e] = a1; o[2 * e + 1] = a2;
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -327,6 +361,19 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   }
 }
 
+// rows per block of the split-K reduce kernel; with statistics it must divide Ho*Wo (0: cannot fuse)
+int splitk_rows_per_block(const ConvParams& p, bool stats) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int HoWo = p.Ho * p.Wo;
+  int rpb = 64;
+  while (rpb > 4 && M / rpb < 1024) rpb >>= 1;
+  if (stats) {
+    while (rpb > 1 && HoWo % rpb) rpb >>= 1;
+    if (HoWo % rpb || HoWo / rpb > 256) return 0;
+  }
+  return rpb;
+}
+
 size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit) {
   conv_pick(p, tile_cfg, ksplit);
   if (ksplit <= 1) return 0;
@@ -358,7 +405,8 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   conv_pick(p, tile_cfg, ksplit);
   p.ksplit = ksplit;
-  if (p.ostat && (ksplit > 1 || tile_cfg < 5)) { set_error("conv: fused output statistics need the halo kernel without split-K"); return SR3_E_UNSUPPORTED; }
+  if (p.ostat && ksplit == 1 && tile_cfg < 5) { set_error("conv: fused output statistics need the halo kernel or split-K"); return SR3_E_UNSUPPORTED; }
+  if (p.ostat && ksplit > 1 && splitk_rows_per_block(p, true) == 0) { set_error("conv: Ho*Wo does not allow fused split-K statistics"); return SR3_E_UNSUPPORTED; }
   { static const char* e = getenv("SR3_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (ksplit > 1) {
     const size_t need = (size_t)ksplit * p.B * p.Ho * p.Wo * p.Cout * sizeof(float);
@@ -385,10 +433,9 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   if (rc) return rc;
   if (ksplit > 1) {
-    const size_t total = (size_t)p.B * p.Ho * p.Wo * (p.Cout >> 2);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, st, p);
+    const int rpb = splitk_rows_per_block(p, p.ostat != nullptr);
+    const long M = (long)p.B * p.Ho * p.Wo;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, p, rpb);
     SR3_LAUNCH_CHECK("k_splitk_reduce");
   }
   return SR3_OK;

@@ -443,6 +443,12 @@ struct Builder {
         stat_slot(out, halo_stats_slices(hg));
         o.has_ostat = true; o.f = T[out].stat_off;
       }
+    } else if (want_stats && P->fuse_stats && o.ksplit > 1) {
+      const int rpb = splitk_rows_per_block(c, true);      // statistics come out of the split-K reduce
+      if (rpb > 0) {
+        stat_slot(out, (Ho * Wo) / rpb);
+        o.has_ostat = true; o.f = T[out].stat_off;
+      }
     }
     ops.push_back(o);
     flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(C0 + C1) * ksize * ksize;
@@ -852,13 +858,16 @@ int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, 
   return chan_stats(x, B, HW, C, stat, static_cast<hipStream_t>(stream));
 }
 int sr3_groupnorm_stats_slices(int B, int HW, int C) { return chan_stats_slices(B, HW, C); }
-int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cout, int tile_cfg) {
+int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int tile_cfg, int ksplit) {
   ConvParams c;
   memset(&c, 0, sizeof(c));
   c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = 1; c.ksize = 3; c.Ho = Hs << ups; c.Wo = Ws << ups;
-  c.Cout = Cout; c.C0 = 32;
-  int ks = 1;
-  conv_pick(c, tile_cfg, ks);
+  c.Cout = Cout; c.C0 = Cin;
+  conv_pick(c, tile_cfg, ksplit);
+  if (ksplit > 1) {
+    const int rpb = splitk_rows_per_block(c, true);
+    return rpb > 0 ? (c.Ho * c.Wo) / rpb : 0;
+  }
   HaloGeom g;
   if (tile_cfg < 5 || !halo_geometry(c, tile_cfg, &g)) return 0;
   return halo_stats_slices(g);

@@ -102,15 +102,21 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ s
   const int cpg = C / groups;
   const int lane = threadIdx.x;
   double s = 0.0, s2 = 0.0;
-  for (int k = 0; k < cpg; ++k) {
-    const int c = g * cpg + k;
-    const bool second = c >= C0;
-    const double* base = second ? st1 : st0;
-    const int Cs = second ? C1 : C0, Ts = second ? T1 : T0, cs = second ? c - C0 : c;
-    for (int t = lane; t < Ts; t += 64) {
-      const double* q = base + (((size_t)b * Ts + t) * Cs + cs) * 2;
-      s += q[0]; s2 += q[1];
-    }
+  // the group's channels [c_lo, c_hi) split at the concat seam; each part is a flat (channel, partial)
+  // index space walked by the 64 lanes: independent loads, fixed summation order
+  const int c_lo = g * cpg, c_hi = c_lo + cpg;
+  const int n0 = max(0, min(c_hi, C0) - c_lo);            // channels of this group that live in src0
+  for (int idx = lane; idx < n0 * T0; idx += 64) {
+    const int k = idx / T0, t = idx - k * T0;
+    const double* q = st0 + (((size_t)b * T0 + t) * C0 + (c_lo + k)) * 2;
+    s += q[0]; s2 += q[1];
+  }
+  const int n1 = cpg - n0;
+  const int c1_lo = max(c_lo, C0) - C0;
+  for (int idx = lane; idx < n1 * T1; idx += 64) {
+    const int k = idx / T1, t = idx - k * T1;
+    const double* q = st1 + (((size_t)b * T1 + t) * C1 + (c1_lo + k)) * 2;
+    s += q[0]; s2 += q[1];
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m); s2 += __shfl_xor(s2, m); }

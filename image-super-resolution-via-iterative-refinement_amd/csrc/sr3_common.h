@@ -73,6 +73,7 @@ int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_sc
 // scratch bytes the auto heuristic may ask for (upper bound) for this problem
 size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
+int splitk_rows_per_block(const ConvParams& p, bool stats);
 struct HaloGeom {
   int TH, TW, NB;          // spatial tile per image, images per workgroup tile (TH*TW*NB = BM)
   int log_tw, log_thw;     // log2(TW), log2(TH*TW)

@@ -161,7 +161,7 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
 int sr3_groupnorm_stats_slices(int B, int HW, int C);
 int sr3_groupnorm_stats_f32(const float* x_nhwc, int B, int HW, int C, double* stat, void* stream);
 /* T of the partial statistics sr3_conv_f32 writes into out_stats (0: this geometry cannot fuse them) */
-int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cout, int tile_cfg);
+int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int tile_cfg, int ksplit);
 /* fold partial statistics of the concat (stat0|stat1) with gamma/beta into ss[B][C0+C1][2] */
 int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW,
                            int groups, const float* gamma, const float* beta, float eps, float* ss, void* stream);

@@ -49,7 +49,7 @@ def conv_call(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, re
     out = torch.full((B, Ho, Wo, Cout), float('nan'), device=d)
     stats = None
     if want_stats:
-        Tst = int(lib.sr3_conv_stats_slices(B, Hs, Ws, ups, Cout, tile_cfg))
+        Tst = int(lib.sr3_conv_stats_slices(B, Hs, Ws, ups, Cin, Cout, tile_cfg, ksplit))
         stats = torch.full((B, max(Tst, 1), Cout, 2), float('nan'), dtype=torch.float64, device=d)
     nb = int(lib.sr3_conv_scratch_bytes(B, Ho, Wo, Cin, Cout, k, tile_cfg, ksplit))
     scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
