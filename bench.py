@@ -131,22 +131,29 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             a[0] += ms[i]
             a[1] += fl[i]
             a[2] += 1
-    halo = [agg[k] for k in (55, 56) if k in agg]
-    t_ms = sum(a[0] for a in halo)
-    flops = sum(a[1] for a in halo)
-    launches = sum(a[2] for a in halo)
+    names = {55: 'k_conv3x3_halo<2,2,false>', 56: 'k_conv3x3_halo<4,1,false>', 57: 'k_conv3x3_halo<2,2,true>',
+             58: 'k_conv3x3_halo<4,1,true>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
+    dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
+    t_ms, flops, launches = agg[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    halo_all = [agg[k] for k in names if k in agg]
+    all_tf = sum(a[1] for a in halo_all) / (sum(a[0] for a in halo_all) * 1e-3) / 1e12
     detail = {str(k): dict(ms_per_forward=v[0] / reps, launches_per_forward=v[2] // reps,
                            tflops=(v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[1] > 0 else None))
               for k, v in sorted(agg.items())}
-    return dict(bound='mfma', kernel='k_conv3x3_halo (v_mfma_f32_32x32x2_f32)', achieved=achieved,
-                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                avg_launch_us=(t_ms / launches * 1e3 if launches else None),
-                launches_per_forward=launches // reps if reps else 0,
-                flops_per_launch=(flops / launches if launches else None),
-                share_of_forward_time=(t_ms / reps) / total_ms if total_ms > 0 else None,
-                by_op_kind=detail)
+    traffic = None
+    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
+        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
+            traffic = json.load(f)['sr3::' + names[dom].replace(',', ', ')]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+    return dict(bound='mfma', kernel=names[dom] + ' (v_mfma_f32_32x32x2_f32)', achieved=achieved,
+                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
+                traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/r01_bench_hbm_pmc.csv',
+                avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,
+                flops_per_launch=flops / launches, share_of_forward_time=(t_ms / reps) / total_ms,
+                all_halo_kernels_tflops=all_tf, by_op_kind=detail)
 
 
 def main():

@@ -311,6 +311,9 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
 }
 }  // namespace
 
+static thread_local hipEvent_t g_mid_event = nullptr;
+void conv_set_mid_event(hipEvent_t ev) { g_mid_event = ev; }
+
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   const int M = p.B * p.Ho * p.Wo;
   const int Cin = p.C0 + p.C1;
@@ -433,6 +436,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   if (rc) return rc;
   if (ksplit > 1) {
+    if (g_mid_event) { SR3_HIP(hipEventRecord(g_mid_event, st)); g_mid_event = nullptr; }
     const int rpb = splitk_rows_per_block(p, p.ostat != nullptr);
     const long M = (long)p.B * p.Ho * p.Wo;
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, p, rpb);

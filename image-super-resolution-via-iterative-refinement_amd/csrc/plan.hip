@@ -582,7 +582,7 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
 static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_channels, const float* level,
                        const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
                        const float* params, char* ws, float* eps_out, int B, hipStream_t st,
-                       hipEvent_t* ev = nullptr) {
+                       hipEvent_t* ev = nullptr, hipEvent_t* mid = nullptr) {
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
   float* ss = reinterpret_cast<float*>(ws + P->ss_off);
@@ -645,6 +645,7 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
           c.x2_w = params + o.p2;
           c.x2_bias = params + o.p3;
         }
+        if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
         rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + P->scratch_off), P->scratch_bytes, st);
         break;
       }
@@ -766,37 +767,47 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
   if (rc) return rc;
   if (workspace_bytes < plan->ws_bytes) { set_error("workspace too small"); return SR3_E_NOMEM; }
   const int n = (int)plan->ops.size();
-  if (n > max_ops) { set_error("op buffer too small: %d < %d", max_ops, n); return SR3_E_NOMEM; }
-  std::vector<hipEvent_t> ev(n + 1);
+  std::vector<hipEvent_t> ev(n + 1), mid(n);
   for (auto& e : ev) SR3_HIP(hipEventCreate(&e));
+  for (auto& e : mid) SR3_HIP(hipEventCreate(&e));
   hipStream_t st = static_cast<hipStream_t>(stream);
   rc = run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr, nullptr, params,
-                   static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data());
+                   static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data(), mid.data());
   if (!rc) {
     hipError_t e = hipEventSynchronize(ev[n]);
     if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");
   }
   if (!rc) {
-    for (int i = 0; i < n; ++i) {
+    int w = 0;
+    for (int i = 0; i < n && !rc; ++i) {
       float ms = 0.f;
       hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
-      op_ms[i] = ms;
       const Op& o = plan->ops[i];
       int kind = (int)o.kind * 10;
       double fl = 0.0;
+      float red_ms = -1.f;
       if (o.kind == OP_CONV) {
-        kind += o.tile_cfg;      // 5x: 51-54 im2col kernel tile configs, 55/56 halo-tile 3x3 kernel
+        // 51-54 im2col kernel tile configs; 55/56 halo-tile 3x3 kernel (57/58: with the fused 1x1 segment)
+        kind += o.tile_cfg + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
         const ConvParams& c = o.cp;
-        fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * (double)(c.C0 + c.C1) * c.ksize * c.ksize;
+        fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)(c.C0 + c.C1) * c.ksize * c.ksize + (o.has_x2 ? c.x2_C0 + c.x2_C1 : 0));
+        if (o.ksplit > 1) {      // split the op into its GEMM kernel and its split-K reduce kernel
+          float a = 0.f;
+          hipEventElapsedTime(&a, ev[i], mid[i]);
+          red_ms = ms - a;
+          ms = a;
+        }
       } else if (o.kind == OP_ATTN) {
         fl = 4.0 * batch * (double)o.i0 * (double)o.i0 * o.i1;
       }
-      op_kind[i] = kind;
-      op_flops[i] = fl;
+      if (w + 2 > max_ops) { set_error("op buffer too small"); rc = SR3_E_NOMEM; break; }
+      op_ms[w] = ms; op_kind[w] = kind; op_flops[w] = fl; ++w;
+      if (red_ms >= 0.f) { op_ms[w] = red_ms; op_kind[w] = 59; op_flops[w] = 0.0; ++w; }
     }
-    *n_ops = n;
+    *n_ops = w;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
+  for (auto& e : mid) (void)hipEventDestroy(e);
   return rc;
 }
 

@@ -74,6 +74,9 @@ int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_sc
 size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
 int splitk_rows_per_block(const ConvParams& p, bool stats);
+// profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the
+// split-K reduce kernel (then resets the pointer).  Thread-local.
+void conv_set_mid_event(hipEvent_t ev);
 struct HaloGeom {
   int TH, TW, NB;          // spatial tile per image, images per workgroup tile (TH*TW*NB = BM)
   int log_tw, log_thw;     // log2(TW), log2(TH*TW)

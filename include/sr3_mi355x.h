@@ -108,8 +108,10 @@ int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw
 
 /* Same forward, run eagerly with a hipEvent pair around every launch of the plan (events are
  * recorded on `stream`).  Measurement aid for bench.py's roofline leg; not capturable.
- * op_kind: OpKind*10 (+ tile_cfg for convs: 51..54 im2col implicit GEMM, 55/56 halo-tile 3x3);
- * op_flops: algorithmic FLOPs of contractions (0 for the HBM-bound helpers). */
+ * One entry per kernel launch.  op_kind: 10 embed+FiLM, 20 input conv, 30 GN statistics, 40 GN fold,
+ * 51..54 im2col implicit-GEMM conv (tile config), 55/56 halo-tile 3x3 conv k_conv3x3_halo<2,2,false> /
+ * <4,1,false>, 57/58 the same with the fused 1x1 res_conv segment (<.,.,true>), 59 split-K reduce,
+ * 60 attention, 70 output Block.  op_flops: algorithmic FLOPs of contractions (0 for HBM-bound helpers). */
 int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
                              const float* noise_level, const int64_t* timestep, const float* freq,
                              const float* params, void* workspace, size_t workspace_bytes, float* eps_out_nchw,

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: 2 processes over gloo exercise the sharding / gather / MAX-timing helpers that
+bench.py and multi-GPU sampling use (no collective sits in the data path itself)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, ret):
+    sys.path.insert(0, PKG)
+    import torch.distributed as dist
+    from sr3_hip import dist as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    cond = torch.arange(n_items * 3 * 2 * 2, dtype=torch.float32).view(n_items, 3, 2, 2)
+    seen = []
+
+    def fake_sampler(c):            # stands in for netG.super_resolution on this rank's shard
+        seen.append(c.shape[0])
+        return c * 2 + 1
+    out = D.sample_sharded(fake_sampler, cond, dist=dist, gather=True)
+    ok = torch.equal(out, cond * 2 + 1)
+    lo, hi = D.shard_range(n_items, rank, world)
+    import time
+    dt = D.timed_region(lambda: time.sleep(0.05 * (rank + 1)), dist=dist)
+    ret[rank] = (bool(ok), seen, (lo, hi), dt)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_items', [5, 8, 1])
+def test_sharded_sampling_two_ranks(n_items):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_items, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    covered = []
+    for r in range(world):
+        ok, seen, (lo, hi), dt = ret[r]
+        assert ok
+        covered += list(range(lo, hi))
+        assert seen == ([hi - lo] if hi > lo else [])
+        assert dt >= 0.09            # MAX over ranks: the slower rank slept 0.10 s
+    assert covered == list(range(n_items))
+    assert abs(ret[0][3] - ret[1][3]) < 1e-9     # both ranks report the same (max) time
+
+
+def test_shard_range_balanced():
+    sys.path.insert(0, PKG)
+    from sr3_hip import dist as D
+    for n in (0, 1, 7, 16, 17):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [h - l for l, h in spans]
+            assert max(sizes) - min(sizes) <= 1
