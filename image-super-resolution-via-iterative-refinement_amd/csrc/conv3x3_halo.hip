@@ -222,16 +222,16 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
     int stage = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
       const bool more_chunks = chunk + 1 < c_end;
-      if (more_chunks) load_halo(SEG1{}, chunk + 1);   // in flight across the 9 taps of this chunk
+      if (more_chunks && !(p.dbg & 2)) load_halo(SEG1{}, chunk + 1);   // in flight across the 9 taps of this chunk
 #pragma unroll 1
       for (int tap = 0; tap < 9; ++tap) {
         const bool last_tap = tap == 8;
         const bool more = !last_tap || more_chunks;
-        if (more) load_w(SEG1{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+        if (more && !(p.dbg & 2)) load_w(SEG1{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
         const int fr = tap / 3, fs = tap - fr * 3;
         if (!(p.dbg & 1)) compute(stage, fr * TWp + fs);
-        if (more) store_w(stage ^ 1);
-        if (last_tap && more_chunks) {
+        if (more && !(p.dbg & 2)) store_w(stage ^ 1);
+        if (last_tap && more_chunks && !(p.dbg & 2)) {
           __syncthreads();                          // every wave is done reading the halo tile
           store_halo();
         }

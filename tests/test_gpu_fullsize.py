@@ -1,0 +1,75 @@
+"""Full-size BASELINE.json configurations on the GPU vs the CPU oracle (random-init weights drawn
+in the reference's order), batch 1 so the oracle finishes in seconds:
+  C2 SR3 16->128 (config/sr_sr3_16_128.json), C5 DDPM-128 (config/sample_ddpm_128.json),
+  C4 SR3 64->512 (config/sr_sr3_64_512.json: norm_groups 16, N = 1024 / d = 1024 mid attention).
+Tolerance: 2e-5 * max(1, |ref|_inf) per forward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gpu_util as G                                # noqa: E402
+
+CONFIGS = {
+    'sr3_16_128': dict(which='sr3', in_channel=6, inner=64, groups=None, mults=[1, 2, 4, 8, 8], attn=[16], rb=2, size=128,
+                       cond=True),
+    'ddpm_128': dict(which='ddpm', in_channel=3, inner=64, groups=None, mults=[1, 1, 2, 2, 4, 4], attn=[16], rb=2, size=128,
+                     cond=False),
+    'sr3_64_512': dict(which='sr3', in_channel=6, inner=64, groups=16, mults=[1, 2, 4, 8, 16], attn=[], rb=1, size=512,
+                       cond=True),
+}
+
+
+def make_opt(c, T=2000):
+    sched = dict(schedule='linear', n_timestep=T, linear_start=1e-6, linear_end=1e-2)
+    unet = dict(in_channel=c['in_channel'], out_channel=3, inner_channel=c['inner'], channel_multiplier=c['mults'],
+                attn_res=c['attn'], res_blocks=c['rb'], dropout=0)
+    if c['groups']:
+        unet['norm_groups'] = c['groups']
+    return {'phase': 'train', 'gpu_ids': [0], 'distributed': False, 'path': {'checkpoint': '/tmp', 'resume_state': None},
+            'train': {'optimizer': {'type': 'adam', 'lr': 1e-4}},
+            'model': {'which_model_G': c['which'], 'finetune_norm': False, 'unet': unet,
+                      'beta_schedule': {'train': dict(sched), 'val': dict(sched)},
+                      'diffusion': dict(image_size=c['size'], channels=3, conditional=c['cond'])}}
+
+
+@pytest.mark.parametrize('name', ['sr3_16_128', 'ddpm_128', 'sr3_64_512'])
+def test_fullsize_forward_and_step_vs_oracle(name):
+    from oracle import sr3_oracle as O
+    import model.networks as networks
+    c = CONFIGS[name]
+    opt = make_opt(c)
+    torch.manual_seed(11)
+    netG = networks.define_G(opt)                       # orthogonal init, reference draw order
+    sd = {k: v.clone() for k, v in netG.state_dict().items()}
+    d = G.dev()
+    netG = netG.to(d)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], d)
+    netG.show_progress = False
+    desc = O.desc_from_opt(opt)
+    S = c['size']
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, c['in_channel'], S, S, generator=g)
+    if c['which'] == 'sr3':
+        t = torch.tensor([[0.7312]])
+    else:
+        t = torch.tensor([1234], dtype=torch.long)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, desc, x, t)
+    got = netG.denoise_fn(x.to(d), t.to(d)).cpu()
+    err = G.assert_close(got, ref, what=name + ' eps')
+    # one reverse step with injected noise through the public p_sample
+    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
+    xs = torch.randn(1, 3, S, S, generator=g)
+    z = torch.randn(1, 3, S, S, generator=g)
+    cond = x[:, :3] if c['cond'] else None
+    tt = 1500
+    with torch.no_grad():
+        ref_step = O.p_sample(sd, desc, tab, xs, tt, z, condition_x=cond)
+    if c['which'] == 'sr3':
+        got_step = netG.p_sample(xs.to(d), tt, condition_x=None if cond is None else cond.to(d), noise=z.to(d))
+    else:
+        got_step = netG.p_sample(xs.to(d), torch.full((1,), tt, dtype=torch.long, device=d),
+                                 condition_x=None if cond is None else cond.to(d), noise=z.to(d))
+    G.assert_close(got_step.cpu(), ref_step, what=name + ' p_sample')
+    print('%s: eps max abs err %.2e (|ref|max %.2f)' % (name, err, ref.abs().max().item()))

@@ -130,6 +130,75 @@ def unet_time(B, out_path, fuse):
     print(rec, flush=True)
 
 
+def unet_time_split(B, nsplit, out_path):
+    """One forward of B images as `nsplit` independent graph branches of B/nsplit images each."""
+    d = torch.device('cuda:0')
+    plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    arena = torch.randn(plan.param_floats, device=d) * 0.02
+    freq = plan.default_freq().to(d)
+    Bs = B // nsplit
+    wss = [E.Workspace() for _ in range(nsplit)]
+    x = torch.randn(B, 3, 128, 128, device=d)
+    cond = torch.randn(B, 3, 128, 128, device=d)
+    lvl = torch.full((B,), 0.5, device=d)
+    out = torch.empty(B, 3, 128, 128, device=d)
+    streams = [torch.cuda.Stream(d) for _ in range(nsplit)]
+
+    def fn():
+        cur = torch.cuda.current_stream()
+        for i, s in enumerate(streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                sl = slice(i * Bs, (i + 1) * Bs)
+                E.unet_forward(plan, arena, freq, wss[i], x[sl], cond=cond[sl], noise_level=lvl[sl], out=out[sl])
+        for s in streams:
+            cur.wait_stream(s)
+    ms = time_fn(fn, warm=2, iters=5)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    msg = time_fn(g.replay, warm=2, iters=10)
+    fl = plan.forward_flops(Bs) * nsplit
+    rec = dict(what='unet_forward_split', B=B, nsplit=nsplit, ms_eager=ms, ms_graph=msg, tflops_graph=fl / msg / 1e9,
+               finite=bool(torch.isfinite(out).all()))
+    with open(out_path, 'a') as f:
+        f.write(json.dumps(rec) + '\n')
+    print(rec, flush=True)
+
+
+def config_times(out_path):
+    """Forward timing (hipGraph) of the other BASELINE.json configurations."""
+    d = torch.device('cuda:0')
+    cfgs = [('C2 sr3_16_128 B16', 'sr3', 6, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128, 16, 3),
+            ('C4 sr3_64_512 B4', 'sr3', 6, 64, 16, [1, 2, 4, 8, 16], [], 1, 512, 4, 3),
+            ('C5 ddpm_128 B32', 'ddpm', 3, 64, 32, [1, 1, 2, 2, 4, 4], [16], 2, 128, 32, 0),
+            ('C2 sr3_16_128 B1', 'sr3', 6, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128, 1, 3)]
+    for (name, var, inc, inner, groups, mults, attn, rb, size, B, cc) in cfgs:
+        plan = E.Plan(var, inc, 3, inner, groups, mults, attn, rb, size)
+        arena = torch.randn(plan.param_floats, device=d) * 0.02
+        freq = plan.default_freq().to(d)
+        ws = E.Workspace()
+        x = torch.randn(B, inc - cc, size, size, device=d)
+        cond = torch.randn(B, cc, size, size, device=d) if cc else None
+        out = torch.empty(B, 3, size, size, device=d)
+        kw = dict(noise_level=torch.full((B,), 0.5, device=d)) if var == 'sr3' else dict(timestep=torch.full((B,), 777, device=d, dtype=torch.long))
+        fn = lambda: E.unet_forward(plan, arena, freq, ws, x, cond=cond, out=out, **kw)
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        ms = time_fn(g.replay, warm=2, iters=5)
+        fl = plan.forward_flops(B)
+        rec = dict(what='config_forward', config=name, ms_graph=ms, tflops=fl / ms / 1e9, gflop_per_img=fl / B / 1e9,
+                   img_per_s_2000_steps=B / (2000 * ms * 1e-3), ws_gb=plan.workspace_bytes(B) / 1e9, ops=plan.num_ops(B),
+                   finite=bool(torch.isfinite(out).all()))
+        with open(out_path, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+        print(rec, flush=True)
+        del arena, ws, x, out
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
@@ -140,7 +209,14 @@ if __name__ == '__main__':
     ap.add_argument('--cfgs', default='1,2,3,4')
     ap.add_argument('--kss', default='1,2,4,8')
     ap.add_argument('--tag', default='')
+    ap.add_argument('--split', default='')
+    ap.add_argument('--configs', action='store_true')
     a = ap.parse_args()
+    if a.configs:
+        config_times(os.path.join(OUT, 'probe_configs.jsonl'))
+    if a.split:
+        for ns in [int(v) for v in a.split.split(',')]:
+            unet_time_split(a.batch, ns, os.path.join(OUT, 'probe_unet.jsonl'))
     if a.unet:
         for fuse in (0, 1):
             unet_time(a.batch, os.path.join(OUT, 'probe_unet.jsonl'), fuse)
