@@ -1,0 +1,290 @@
+// Backward of the single-head attention core (autograd of SelfAttention.forward,
+// model/sr3_modules/unet.py:127-139, inside `l_pix.backward()`):
+//   S = Q K^T / sqrt(C), P = softmax(S), O = P V
+//   dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = dS K / sqrt(C) ; dK = dS^T Q / sqrt(C)
+// One workgroup owns 32 query rows of one image: it recomputes the score strip P[32][N] (as the
+// forward does), builds the strip of dS / sqrt(C) next to it in LDS, writes its rows of dQ, and adds
+// its contribution to dK and dV (all keys) with fp32 atomics -- dqkv must be zero on entry.
+// Layouts as in attention.hip: qkv / dqkv [B][N][3C] (q|k|v), dout [B][N][C].  fp32 MFMA throughout.
+#include "sr3_common.h"
+#include "train.h"
+
+namespace sr3 {
+
+constexpr int AB_LDK = 36;
+constexpr int AB_LDV = 132;
+constexpr int AB_QK_STAGE = (32 + 128) * AB_LDK;     // floats
+constexpr int AB_V_STAGE = 32 * AB_LDV;
+
+template <int NSTAGE>
+__global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                        int N, int C, float* __restrict__ dqkv) {
+  extern __shared__ f32x4 smem_v[];
+  float* smem = reinterpret_cast<float*>(smem_v);
+  const int Npad = (N + 31) & ~31;
+  const int LDS_S = Npad + 4;
+  float* P = smem;                        // [32][LDS_S]  softmax probabilities
+  float* D = smem + 32 * LDS_S;           // [32][LDS_S]  dP, then dS / sqrt(C)
+  float* stg = smem + 64 * LDS_S;         // staging
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int m0 = blockIdx.x * 32;
+  const int rs3 = 3 * C;
+  const float* base = qkv + (size_t)b * N * rs3;
+  const float* dob = dout + (size_t)b * N * C;
+  float* dqb = dqkv + (size_t)b * N * rs3;
+  const int kq = tid & 7, lrow = tid >> 3;
+  const int kh = (lane >> 5) * 4;
+  const float sqrt_c = sqrtf((float)C);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  constexpr int QKS = (NSTAGE == 2) ? AB_QK_STAGE : 0;
+
+  // strip[row][key] = sum_c A[row][c] * Bm[key][c]  (A rows: a_ptr + m*a_stride, B rows: b_ptr + key*b_stride)
+  auto strip_gemm = [&](const float* a_ptr, int a_stride, const float* b_ptr, int b_stride, float* strip, bool scale) {
+    const int nc = (C + 31) / 32;
+    const int nkb = (Npad + 127) / 128;
+    const int nsteps = nkb * nc;
+    f32x4 rq, rk[4];
+    bool qok, kok[4];
+    auto load = [&](int s) {
+      const int kb = (s / nc) * 128;
+      const int c = (s % nc) * 32 + kq * 4;
+      const bool cv = c < C;
+      const int m = m0 + lrow;
+      qok = cv && m < N;
+      rq = *reinterpret_cast<const f32x4*>(a_ptr + (qok ? m * a_stride + c : 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = kb + lrow + 32 * i;
+        kok[i] = cv && key < N;
+        rk[i] = *reinterpret_cast<const f32x4*>(b_ptr + (kok[i] ? key * b_stride + c : 0));
+      }
+    };
+    auto store = [&](int st) {
+      float* Qs = stg + st * QKS;
+      float* Ks = Qs + 32 * AB_LDK;
+      *reinterpret_cast<f32x4*>(&Qs[lrow * AB_LDK + kq * 4]) = qok ? rq : zero;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(&Ks[(lrow + 32 * i) * AB_LDK + kq * 4]) = kok[i] ? rk[i] : zero;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    __syncthreads();
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = (NSTAGE == 2) ? (s & 1) : 0;
+      const bool more = s + 1 < nsteps;
+      if (more) load(s + 1);
+      const int kb = (s / nc) * 128;
+      const bool wave_active = (kb + wave * 32) < Npad;
+      if (wave_active) {
+        const float* Qs = stg + cur * QKS;
+        const float* Ks = Qs + 32 * AB_LDK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&Qs[(lane & 31) * AB_LDK + kk * 8 + kh]);
+          const f32x4 k4 = *reinterpret_cast<const f32x4*>(&Ks[(wave * 32 + (lane & 31)) * AB_LDK + kk * 8 + kh]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], k4[q], acc, 0, 0, 0);
+        }
+        if ((s % nc) == nc - 1) {
+          const int key = kb + wave * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            strip[row * LDS_S + key] = scale ? acc[r] / sqrt_c : acc[r];
+            acc[r] = 0.f;
+          }
+        }
+      }
+      if (NSTAGE == 1) __syncthreads();
+      if (more) store((NSTAGE == 2) ? (cur ^ 1) : 0);
+      __syncthreads();
+    }
+  };
+
+  // ---- A: P = softmax(Q K^T / sqrt(C)) ----
+  strip_gemm(base, rs3, base + C, rs3, P, true);
+  {
+    const int row = tid >> 3, sub = tid & 7;
+    float* sr = P + row * LDS_S;
+    float mx = -INFINITY;
+    for (int k = sub; k < N; k += 8) mx = fmaxf(mx, sr[k]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    float sum = 0.f;
+    for (int k = sub; k < N; k += 8) { const float e = expf(sr[k] - mx); sr[k] = e; sum += e; }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    for (int k = sub; k < N; k += 8) sr[k] = sr[k] / sum;
+    for (int k = N + sub; k < Npad; k += 8) sr[k] = 0.f;
+  }
+  // ---- B: dP = dO V^T ----
+  strip_gemm(dob, C, base + 2 * C, rs3, D, false);
+  // ---- C: dS / sqrt(C) = P o (dP - rowsum(dP o P)) / sqrt(C)  (rows m >= N have dO = 0 => dS = 0) ----
+  {
+    const int row = tid >> 3, sub = tid & 7;
+    const float* pr = P + row * LDS_S;
+    float* dr = D + row * LDS_S;
+    float rs = 0.f;
+    for (int k = sub; k < N; k += 8) rs += dr[k] * pr[k];
+    rs += __shfl_xor(rs, 1);
+    rs += __shfl_xor(rs, 2);
+    rs += __shfl_xor(rs, 4);
+    for (int k = sub; k < N; k += 8) dr[k] = pr[k] * (dr[k] - rs) / sqrt_c;
+    for (int k = N + sub; k < Npad; k += 8) dr[k] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- D: dQ[32][C] = (dS / sqrt(C)) K ----
+  {
+    const int npan = (C + 127) / 128;
+    const int nk = Npad / 32;
+    const int nsteps = npan * nk;
+    constexpr int VS = (NSTAGE == 2) ? AB_V_STAGE : 0;
+    f32x4 rv[4];
+    bool vok[4];
+    auto load = [&](int s) {
+      const int cp = (s / nk) * 128;
+      const int k0 = (s % nk) * 32;
+      const int c = cp + (tid & 31) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = k0 + (tid >> 5) + 8 * i;
+        vok[i] = key < N && c < C;
+        rv[i] = *reinterpret_cast<const f32x4*>(base + (vok[i] ? key * rs3 + C + c : 0));
+      }
+    };
+    auto store = [&](int st) {
+      float* Vs = stg + st * VS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(&Vs[((tid >> 5) + 8 * i) * AB_LDV + (tid & 31) * 4]) = vok[i] ? rv[i] : zero;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+      const int cur = (NSTAGE == 2) ? (s & 1) : 0;
+      const bool more = s + 1 < nsteps;
+      if (more) load(s + 1);
+      const int cp = (s / nk) * 128;
+      const int k0 = (s % nk) * 32;
+      const bool wave_active = (cp + wave * 32) < C;
+      if (wave_active) {
+        const float* Vs = stg + cur * VS;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(&D[(lane & 31) * LDS_S + k0 + kk * 8 + kh]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float bv = Vs[(kk * 8 + kh + q) * AB_LDV + wave * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bv, acc, 0, 0, 0);
+          }
+        }
+        if ((s % nk) == nk - 1) {
+          const int c = cp + wave * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < N && c < C) dqb[(size_t)m * rs3 + c] = acc[r];
+            acc[r] = 0.f;
+          }
+        }
+      }
+      if (NSTAGE == 1) __syncthreads();
+      if (more) store((NSTAGE == 2) ? (cur ^ 1) : 0);
+      __syncthreads();
+    }
+  }
+
+  // ---- E: dK += (dS/sqrt(C))^T Q ; dV += P^T dO   (this workgroup's 32 rows, all keys) ----
+  {
+    float* Qt = stg;                       // [32 rows][AB_LDV]
+    float* Ot = stg + AB_V_STAGE;          // [32 rows][AB_LDV]
+    const int npan = (C + 127) / 128;
+    for (int pn = 0; pn < npan; ++pn) {
+      const int cp = pn * 128;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 5) + 8 * i;
+        const int c = cp + (tid & 31) * 4;
+        const int m = m0 + row;
+        const bool ok = m < N && c < C;
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(base + (ok ? m * rs3 + c : 0));
+        const f32x4 ov = *reinterpret_cast<const f32x4*>(dob + (ok ? m * C + c : 0));
+        *reinterpret_cast<f32x4*>(&Qt[row * AB_LDV + (tid & 31) * 4]) = ok ? qv : zero;
+        *reinterpret_cast<f32x4*>(&Ot[row * AB_LDV + (tid & 31) * 4]) = ok ? ov : zero;
+      }
+      __syncthreads();
+      const int c = cp + wave * 32 + (lane & 31);
+      if (cp + wave * 32 < C) {
+        for (int kb = 0; kb < Npad; kb += 32) {
+          f32x16 ak, av;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { ak[r] = 0.f; av[r] = 0.f; }
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            const int row = 2 * kk + (lane >> 5);
+            const float ds = D[row * LDS_S + kb + (lane & 31)];     // A[i = key][k = row]
+            const float pp = P[row * LDS_S + kb + (lane & 31)];
+            const float qv = Qt[row * AB_LDV + wave * 32 + (lane & 31)];   // B[k = row][j = c]
+            const float ov = Ot[row * AB_LDV + wave * 32 + (lane & 31)];
+            ak = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qv, ak, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(pp, ov, av, 0, 0, 0);
+          }
+          if (c < C) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              if (key < N) {
+                atomicAdd(&dqb[(size_t)key * rs3 + C + c], ak[r]);
+                atomicAdd(&dqb[(size_t)key * rs3 + 2 * C + c], av[r]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+int attention_backward(const float* qkv, const float* dout, int B, int N, int C, float* dqkv, hipStream_t st) {
+  if (C & 3) { set_error("attention_bwd: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  if ((double)B * N * 3.0 * C >= 2147483647.0) { set_error("attention_bwd: qkv exceeds 2^31 elements"); return SR3_E_UNSUPPORTED; }
+  const int Npad = (N + 31) & ~31;
+  const size_t strips = (size_t)64 * (Npad + 4);
+  int nstage = 2;
+  size_t stage_f = 2 * (size_t)(AB_QK_STAGE > AB_V_STAGE ? AB_QK_STAGE : AB_V_STAGE);
+  if (stage_f < 2 * (size_t)AB_V_STAGE) stage_f = 2 * (size_t)AB_V_STAGE;
+  size_t smem = (strips + stage_f) * sizeof(float);
+  if (smem > 160 * 1024) {
+    nstage = 1;
+    stage_f = (size_t)(AB_QK_STAGE > 2 * AB_V_STAGE ? AB_QK_STAGE : 2 * AB_V_STAGE);
+    smem = (strips + stage_f) * sizeof(float);
+  }
+  if (smem > 160 * 1024) { set_error("attention_bwd: N=%d does not fit the LDS strips", N); return SR3_E_UNSUPPORTED; }
+  SR3_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * N * 3 * C * sizeof(float), st));
+  static size_t attr_max[3] = {0, 0, 0};
+  auto kern = nstage == 2 ? k_attention_bwd<2> : k_attention_bwd<1>;
+  if (smem > attr_max[nstage]) {
+    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    attr_max[nstage] = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((N + 31) / 32, B), dim3(256), smem, st, qkv, dout, N, C, dqkv);
+  SR3_LAUNCH_CHECK("k_attention_bwd");
+  return SR3_OK;
+}
+
+}  // namespace sr3

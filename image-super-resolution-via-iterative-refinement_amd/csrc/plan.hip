@@ -13,8 +13,8 @@
 #include <string>
 #include <vector>
 
-#include "../../include/sr3_mi355x.h"
-#include "sr3_common.h"
+#include "plan_internal.h"
+#include "train.h"
 
 namespace sr3 {
 
@@ -35,79 +35,7 @@ int hip_fail(hipError_t e, const char* what) {
 }
 const char* last_error() { return g_err; }
 
-// ---------------------------------------------------------------------------------------------
-// plan data
-// ---------------------------------------------------------------------------------------------
-struct Tensor {
-  size_t off = 0;       // byte offset in the workspace
-  size_t bytes = 0;
-  int C = 0, H = 0, W = 0;
-  size_t stat_off = 0;  // byte offset of the partial statistics [B][T][C][2] doubles (valid once stats_done)
-  int stat_T = 0;       // partials per image
-  bool stats_done = false;
-  bool valid = false;
-};
-
-struct ResLayer {
-  std::string name;     // e.g. "downs.1"
-  int cin, cout, skip;  // cin includes skip
-  bool attn;
-  int film_off;         // row offset in the FiLM table
-  size_t gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, rc_w, rc_b;
-  bool has_rc;
-  size_t an_w, an_b, qkv_w, ao_w, ao_b;
-};
-
-struct Layer {
-  int kind;  // 0 conv_in, 1 res, 2 down, 3 up
-  std::string name;
-  int cin, cout;
-  size_t w, b;  // conv_in / down / up
-  ResLayer res;
-};
-
-enum OpKind { OP_MEMSET, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_ATTN, OP_CONV_OUT };
-
-struct Op {
-  OpKind kind;
-  // generic offsets (bytes into workspace unless noted)
-  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, g = 0, h = 0;
-  size_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;   // float offsets into the parameter arena
-  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
-  bool has_src1 = false, has_bias = false, has_film = false, has_res = false, has_res1 = false, has_ostat = false,
-       has_st1 = false, has_x2 = false, has_x21 = false;
-  ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
-  int tile_cfg = 0, ksplit = 0;
-};
-
-struct Tap { std::string name; size_t off; int C, H, W; };
-
 }  // namespace sr3
-
-using namespace sr3;
-
-struct sr3_plan {
-  sr3_unet_desc d;
-  std::vector<sr3_param_info> params;
-  std::map<std::string, int> pindex;
-  size_t param_floats = 0;
-  int F = 0;
-  size_t film_w = 0, film_b = 0;
-  size_t emb_w1 = 0, emb_b1 = 0, emb_w2 = 0, emb_b2 = 0;
-  std::vector<Layer> downs, mid, ups;
-  size_t fin_gn_w = 0, fin_gn_b = 0, fin_w = 0, fin_b = 0;
-  int fin_cin = 0, out_ch = 0;
-  // options
-  int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0;
-  // compiled forward
-  int built_batch = -1;
-  int built_cond = -1;
-  std::vector<Op> ops;
-  std::vector<Tap> taps;
-  size_t ws_bytes = 0;
-  size_t stats_off = 0, stats_bytes = 0, ss_off = 0, temb_off = 0, film_off = 0, scratch_off = 0, scratch_bytes = 0;
-  double flops = 0;
-};
 
 namespace sr3 {
 
@@ -360,7 +288,12 @@ struct Builder {
   int max_cin = 0;
   double flops = 0;
   std::vector<Op>& ops;
-  Builder(sr3_plan* p, int b) : P(p), B(b), ops(p->ops) {}
+  bool train = false;
+  size_t gn_cursor = 0, mr_cursor = 0;     // train: persistent per-GroupNorm tables
+  size_t cur_ss = 0, cur_mr = 0;           // tables written by the most recent fold
+  size_t cur_gamma = 0, cur_beta = 0;
+  size_t max_dA = 0, max_wt = 0, max_slab = 0, max_part = 0, max_z = 0, max_dq = 0;
+  Builder(sr3_plan* p, int b, bool tr = false) : P(p), B(b), ops(tr ? p->tops : p->ops), train(tr) {}
 
   int make(int C, int H, int W) {
     Tensor t;
@@ -373,6 +306,7 @@ struct Builder {
   }
   void drop(int h) {
     if (h < 0 || !T[h].valid) return;
+    if (train) return;                     // the backward needs every activation
     if (!P->keep_all) act.release(T[h].off, T[h].bytes);
     T[h].valid = false;
   }
@@ -400,8 +334,15 @@ struct Builder {
     if (x1 >= 0) { o.b = T[x1].stat_off; o.i1 = T[x1].C; o.i4 = T[x1].stat_T; }
     o.i2 = T[x0].H * T[x0].W;
     o.p0 = gamma; o.p1 = beta;
+    const int Cf = T[x0].C + (x1 >= 0 ? T[x1].C : 0);
+    if (train) {
+      o.ss_rel = gn_cursor; gn_cursor += ((size_t)B * Cf * 2 * sizeof(float) + 255) & ~(size_t)255;
+      o.mr_rel = mr_cursor; mr_cursor += ((size_t)B * P->d.norm_groups * 2 * sizeof(float) + 255) & ~(size_t)255;
+      o.has_mr = true;
+    }
+    cur_ss = o.ss_rel; cur_mr = o.mr_rel; cur_gamma = gamma; cur_beta = beta;
     ops.push_back(o);
-    max_cin = std::max(max_cin, T[x0].C + (x1 >= 0 ? T[x1].C : 0));
+    max_cin = std::max(max_cin, Cf);
   }
   // generic conv over the virtual concat (x0|x1); residual is the concat view (r0|r1)
   int conv(int x0, int x1, int Cout, int ksize, int stride, int ups, int act_mode, size_t w, bool has_bias,
@@ -428,7 +369,26 @@ struct Builder {
     o.has_res1 = r1 >= 0; if (r1 >= 0) o.d = T[r1].off;
     o.e = T[out].off;
     o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
+    o.ss_rel = act_mode ? cur_ss : 0;
     conv_pick(c, o.tile_cfg, o.ksplit);
+    if (train) {
+      Rec r;
+      r.kind = R_CONV; r.x0 = x0; r.x1 = x1; r.out = out; r.r0 = r0; r.r1 = r1; r.q0 = q0; r.q1 = q1;
+      r.ksize = ksize; r.stride = stride; r.ups = ups; r.act = act_mode; r.film_row = film_row;
+      r.w = w; r.bias = bias; r.has_bias = has_bias; r.qw = qw; r.qb = qb; r.has_q = q0 >= 0;
+      r.gamma = cur_gamma; r.beta = cur_beta; r.ss_off = cur_ss; r.mr_off = cur_mr;
+      P->recs.push_back(r);
+      // scratch the backward of this conv needs
+      const size_t cin = (size_t)(C0 + C1);
+      max_dA = std::max(max_dA, (size_t)B * Hi * Wi * cin * sizeof(float));
+      max_wt = std::max(max_wt, (size_t)Cout * ksize * ksize * cin * sizeof(float));
+      if (q0 >= 0) {
+        const size_t cq = (size_t)T[q0].C + (q1 >= 0 ? T[q1].C : 0);
+        max_dq = std::max(max_dq, (size_t)B * Ho * Wo * cq * sizeof(float));
+        max_wt = std::max(max_wt, (size_t)Cout * cq * sizeof(float));
+      }
+      if (stride == 2) max_z = std::max(max_z, (size_t)B * 4 * Ho * Wo * Cout * sizeof(float));
+    }
     if (q0 >= 0) {   // fused 1x1 segment (res_conv); caller checked can_fuse_x2()
       c.x2_C0 = T[q0].C; c.x2_C1 = q1 >= 0 ? T[q1].C : 0;
       o.has_x2 = true; o.g = T[q0].off; o.has_x21 = q1 >= 0; if (q1 >= 0) o.h = T[q1].off;
@@ -487,6 +447,7 @@ struct Builder {
       Op a; a.kind = OP_ATTN;
       a.a = T[qkv].off; a.b = T[o].off; a.i0 = T[out].H * T[out].W; a.i1 = R.cout;
       ops.push_back(a);
+      if (train) { Rec r; r.kind = R_ATTN; r.qkv = qkv; r.o = o; P->recs.push_back(r); }
       flops += 4.0 * B * (double)a.i0 * (double)a.i0 * R.cout;
       drop(qkv);
       const int out2 = conv(o, -1, R.cout, 1, 1, 0, 0, R.ao_w, true, R.ao_b, -1, out, -1, true);
@@ -498,21 +459,19 @@ struct Builder {
   }
 };
 
-static int build_forward(sr3_plan* P, int B, int cond_channels) {
-  if (P->built_batch == B && P->built_cond == cond_channels) return SR3_OK;
+// the UNet.forward walk (downs -> mid -> ups -> final), emitting ops through the builder
+static void walk_forward(sr3_plan* P, Builder& bld, int cond_channels) {
   const sr3_unet_desc& d = P->d;
-  if (B <= 0) { set_error("batch must be > 0"); return SR3_E_BADARG; }
-  if (cond_channels < 0 || cond_channels >= d.in_channel) { set_error("cond_channels %d out of range (in_channel %d)", cond_channels, d.in_channel); return SR3_E_BADARG; }
-  P->ops.clear();
-  P->taps.clear();
-  Builder bld(P, B);
-  std::vector<Op>& ops = P->ops;
+  std::vector<Op>& ops = bld.ops;
+  const int B = bld.B;
   const int S = d.image_size, inner = d.inner_channel;
 
   { Op o; o.kind = OP_EMBED; ops.push_back(o); }
   bld.flops += 2.0 * B * (2.0 * 4 * inner * inner + (double)P->F * inner);
 
-  auto tap = [&](const std::string& name, int h) { P->taps.push_back({name, bld.T[h].off, bld.T[h].C, bld.T[h].H, bld.T[h].W}); };
+  auto tap = [&](const std::string& name, int h) {
+    if (!bld.train) P->taps.push_back({name, bld.T[h].off, bld.T[h].C, bld.T[h].H, bld.T[h].W});
+  };
   std::vector<int> feats;
   int cur = -1;
   for (auto& L : P->downs) {
@@ -522,6 +481,7 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
       o.e = bld.T[cur].off; o.p0 = L.w; o.p1 = L.b;
       o.i0 = d.in_channel - cond_channels; o.i1 = cond_channels; o.i2 = L.cout; o.i3 = S;
       ops.push_back(o);
+      if (bld.train) { Rec r; r.kind = R_CONV_IN; r.out = cur; r.w = L.w; r.bias = L.b; P->recs.push_back(r); }
       bld.flops += 2.0 * B * S * S * (double)L.cout * L.cin * 9;
     } else if (L.kind == 1) {
       cur = bld.res_block(cur, -1, L.res);   // the input stays alive: it is a skip feature
@@ -559,9 +519,27 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
   {
     Op o; o.kind = OP_CONV_OUT;
     o.a = bld.T[cur].off; o.p0 = P->fin_w; o.p1 = P->fin_b; o.i0 = bld.T[cur].C; o.i1 = P->out_ch; o.i2 = S;
+    o.ss_rel = bld.cur_ss;
     ops.push_back(o);
+    if (bld.train) {
+      Rec r; r.kind = R_CONV_OUT; r.x0 = cur; r.w = P->fin_w; r.bias = P->fin_b; r.gamma = P->fin_gn_w; r.beta = P->fin_gn_b;
+      r.ss_off = bld.cur_ss; r.mr_off = bld.cur_mr; r.act = 2;
+      P->recs.push_back(r);
+    }
     bld.flops += 2.0 * B * S * S * (double)P->out_ch * bld.T[cur].C * 9;
   }
+}
+
+static int build_forward(sr3_plan* P, int B, int cond_channels) {
+  if (P->built_batch == B && P->built_cond == cond_channels) return SR3_OK;
+  const sr3_unet_desc& d = P->d;
+  if (B <= 0) { set_error("batch must be > 0"); return SR3_E_BADARG; }
+  if (cond_channels < 0 || cond_channels >= d.in_channel) { set_error("cond_channels %d out of range (in_channel %d)", cond_channels, d.in_channel); return SR3_E_BADARG; }
+  P->ops.clear();
+  P->taps.clear();
+  Builder bld(P, B);
+  const int inner = d.inner_channel;
+  walk_forward(P, bld, cond_channels);
   // ---- fixed regions after the activation arena (high-water mark) ----
   size_t off = (bld.act.high + 255) & ~(size_t)255;
   P->stats_off = off; P->stats_bytes = bld.stats_cursor; off += (bld.stats_cursor + 255) & ~(size_t)255;
@@ -579,16 +557,22 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
 // ---------------------------------------------------------------------------------------------
 // forward driver
 // ---------------------------------------------------------------------------------------------
-static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_channels, const float* level,
-                       const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
-                       const float* params, char* ws, float* eps_out, int B, hipStream_t st,
-                       hipEvent_t* ev = nullptr, hipEvent_t* mid = nullptr) {
+Regions infer_regions(const sr3_plan* P) {
+  Regions r;
+  r.ops = &P->ops; r.stats_off = P->stats_off; r.ss_off = P->ss_off; r.mr_off = 0; r.temb_off = P->temb_off;
+  r.film_off = P->film_off; r.scratch_off = P->scratch_off; r.scratch_bytes = P->scratch_bytes;
+  return r;
+}
+
+int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
+                const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
+                const float* params, char* ws, float* eps_out, int B, hipStream_t st,
+                hipEvent_t* ev, hipEvent_t* mid) {
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
-  float* ss = reinterpret_cast<float*>(ws + P->ss_off);
-  float* film = reinterpret_cast<float*>(ws + P->film_off);
+  float* film = reinterpret_cast<float*>(ws + R.film_off);
   int last_hw = 0;
-  for (const Op& o : P->ops) {
+  for (const Op& o : *R.ops) {
     int rc = SR3_OK;
     if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
     ++op_index;
@@ -602,7 +586,7 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
         e.level = level; e.tstep = tstep; e.level_table = level_table; e.step_dev = step_dev; e.freq = freq;
         e.w1 = params + P->emb_w1; e.b1 = params + P->emb_b1; e.w2 = params + P->emb_w2; e.b2 = params + P->emb_b2;
         e.wf = params + P->film_w; e.bf = params + P->film_b; e.F = P->F;
-        e.temb = reinterpret_cast<float*>(ws + P->temb_off); e.film = film;
+        e.temb = reinterpret_cast<float*>(ws + R.temb_off); e.film = film;
         rc = embed_forward(e, st);
         break;
       }
@@ -618,13 +602,14 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
       }
       case OP_STATS:
         rc = chan_stats(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1,
-                        reinterpret_cast<double*>(ws + P->stats_off + o.b), st);
+                        reinterpret_cast<double*>(ws + R.stats_off + o.b), st);
         break;
       case OP_FOLD:
-        rc = gn_finalize(reinterpret_cast<const double*>(ws + P->stats_off + o.a), o.i0, o.i3,
-                         o.has_st1 ? reinterpret_cast<const double*>(ws + P->stats_off + o.b) : nullptr,
+        rc = gn_finalize(reinterpret_cast<const double*>(ws + R.stats_off + o.a), o.i0, o.i3,
+                         o.has_st1 ? reinterpret_cast<const double*>(ws + R.stats_off + o.b) : nullptr,
                          o.has_st1 ? o.i1 : 0, o.has_st1 ? o.i4 : 0, B, o.i2, d.norm_groups, params + o.p0,
-                         params + o.p1, 1e-5f, ss, st);
+                         params + o.p1, 1e-5f, reinterpret_cast<float*>(ws + R.ss_off + o.ss_rel), st,
+                         o.has_mr ? reinterpret_cast<float*>(ws + R.mr_off + o.mr_rel) : nullptr);
         last_hw = o.i2;
         break;
       case OP_CONV: {
@@ -633,12 +618,12 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
         c.src1 = o.has_src1 ? reinterpret_cast<const float*>(ws + o.b) : nullptr;
         c.w = params + o.p0;
         c.bias = o.has_bias ? params + o.p1 : nullptr;
-        c.ss = c.act ? ss : nullptr;
+        c.ss = c.act ? reinterpret_cast<const float*>(ws + R.ss_off + o.ss_rel) : nullptr;
         c.film = o.has_film ? film + o.i0 : nullptr;
         c.res0 = o.has_res ? reinterpret_cast<const float*>(ws + o.c) : nullptr;
         c.res1 = o.has_res1 ? reinterpret_cast<const float*>(ws + o.d) : nullptr;
         c.out = reinterpret_cast<float*>(ws + o.e);
-        c.ostat = o.has_ostat ? reinterpret_cast<double*>(ws + P->stats_off + o.f) : nullptr;
+        c.ostat = o.has_ostat ? reinterpret_cast<double*>(ws + R.stats_off + o.f) : nullptr;
         if (o.has_x2) {
           c.x2_src0 = reinterpret_cast<const float*>(ws + o.g);
           c.x2_src1 = o.has_x21 ? reinterpret_cast<const float*>(ws + o.h) : nullptr;
@@ -646,7 +631,7 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
           c.x2_bias = params + o.p3;
         }
         if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
-        rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + P->scratch_off), P->scratch_bytes, st);
+        rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + R.scratch_off), R.scratch_bytes, st);
         break;
       }
       case OP_ATTN:
@@ -654,14 +639,116 @@ static int run_forward(sr3_plan* P, const float* x, const float* cond, int cond_
                                reinterpret_cast<float*>(ws + o.b), st);
         break;
       case OP_CONV_OUT:
-        rc = conv_out_nchw(reinterpret_cast<const float*>(ws + o.a), ss, B, o.i2, o.i2, o.i0, params + o.p0,
-                           params + o.p1, o.i1, eps_out, st);
+        rc = conv_out_nchw(reinterpret_cast<const float*>(ws + o.a), reinterpret_cast<const float*>(ws + R.ss_off + o.ss_rel),
+                           B, o.i2, o.i2, o.i0, params + o.p0, params + o.p1, o.i1, eps_out, st);
         break;
     }
     if (rc) return rc;
   }
   if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
   (void)last_hw;
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// training plan: the same forward walk with every activation kept and persistent GroupNorm tables,
+// a gradient mirror of the activation arena, and the scratch the backward walk needs
+// ---------------------------------------------------------------------------------------------
+int build_train(sr3_plan* P, int B, int cond_channels) {
+  if (P->train_batch == B && P->train_cond == cond_channels) return SR3_OK;
+  const sr3_unet_desc& d = P->d;
+  if (B <= 0) { set_error("batch must be > 0"); return SR3_E_BADARG; }
+  if (cond_channels < 0 || cond_channels >= d.in_channel) { set_error("cond_channels out of range"); return SR3_E_BADARG; }
+  P->tops.clear();
+  P->recs.clear();
+  Builder bld(P, B, true);
+  walk_forward(P, bld, cond_channels);
+  P->ttens = bld.T;
+  const int S = d.image_size, inner = d.inner_channel, G = d.norm_groups;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t off = al(bld.act.high);
+  P->t_act_bytes = off;
+  off *= 2;                                   // gradients mirror the activations at +t_act_bytes
+  P->t_stats_off = off; off += al(bld.stats_cursor);
+  P->t_gn_off = off; off += al(bld.gn_cursor);
+  P->t_misc_off = off; off += al(bld.mr_cursor);           // mean / rstd tables
+  P->t_temb_off = off; off += al((size_t)B * inner * sizeof(float));
+  P->t_film_off = off; off += al((size_t)B * P->F * sizeof(float));
+  P->t_scratch_off = off; P->t_scratch_bytes = bld.max_scratch; off += al(bld.max_scratch);
+  // backward scratch
+  size_t max_dA = bld.max_dA, max_wt = bld.max_wt, max_slab = 0, max_part = 0, max_dwtmp = 0;
+  size_t max_bscratch = 0;                    // split-K slabs of the data-gradient convs
+  for (const Rec& r : P->recs) {
+    ConvParams c;
+    memset(&c, 0, sizeof(c));
+    if (r.kind == R_CONV) {
+      const Tensor& x0 = P->ttens[r.x0];
+      const Tensor& o = P->ttens[r.out];
+      c.C0 = x0.C; c.C1 = r.x1 >= 0 ? P->ttens[r.x1].C : 0; c.B = B; c.Hs = x0.H; c.Ws = x0.W; c.ups = r.ups;
+      c.stride = r.stride; c.ksize = r.ksize; c.Ho = o.H; c.Wo = o.W; c.Cout = o.C;
+      max_slab = std::max(max_slab, wgrad_slab_bytes(c, nullptr));
+      max_part = std::max(max_part, act_bwd_part_bytes(B, x0.H * x0.W, c.C0 + c.C1));
+      max_part = std::max(max_part, (size_t)B * chan_stats_slices(B, o.H * o.W, o.C) * o.C * 2 * sizeof(double));
+      // dgrad conv: src = dOut (or its zero-inserted version), Cout' = Cin
+      ConvParams g;
+      memset(&g, 0, sizeof(g));
+      g.C0 = o.C; g.B = B; g.Hs = x0.H << r.ups; g.Ws = x0.W << r.ups; g.stride = 1; g.ksize = r.ksize;
+      g.Ho = g.Hs; g.Wo = g.Ws; g.Cout = c.C0 + c.C1;
+      max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
+      if (r.has_q) {
+        ConvParams q;
+        memset(&q, 0, sizeof(q));
+        q.C0 = P->ttens[r.q0].C; q.C1 = r.q1 >= 0 ? P->ttens[r.q1].C : 0; q.B = B; q.Hs = o.H; q.Ws = o.W; q.stride = 1;
+        q.ksize = 1; q.Ho = o.H; q.Wo = o.W; q.Cout = o.C;
+        max_slab = std::max(max_slab, wgrad_slab_bytes(q, nullptr));
+        ConvParams gq;
+        memset(&gq, 0, sizeof(gq));
+        gq.C0 = o.C; gq.B = B; gq.Hs = o.H; gq.Ws = o.W; gq.stride = 1; gq.ksize = 1; gq.Ho = o.H; gq.Wo = o.W;
+        gq.Cout = q.C0 + q.C1;
+        max_bscratch = std::max(max_bscratch, conv_splitk_bytes(gq, 0, 0));
+      }
+    } else if (r.kind == R_CONV_IN) {
+      c.C0 = 8; c.B = B; c.Hs = S; c.Ws = S; c.stride = 1; c.ksize = 3; c.Ho = S; c.Wo = S; c.Cout = P->ttens[r.out].C;
+      max_slab = std::max(max_slab, wgrad_slab_bytes(c, nullptr));
+      max_dwtmp = std::max(max_dwtmp, (size_t)c.Cout * 9 * 8 * sizeof(float));
+      max_part = std::max(max_part, (size_t)B * chan_stats_slices(B, S * S, c.Cout) * c.Cout * 2 * sizeof(double));
+    } else if (r.kind == R_CONV_OUT) {
+      const Tensor& x0 = P->ttens[r.x0];
+      c.C0 = x0.C; c.B = B; c.Hs = S; c.Ws = S; c.stride = 1; c.ksize = 3; c.Ho = S; c.Wo = S; c.Cout = 4;
+      max_slab = std::max(max_slab, wgrad_slab_bytes(c, nullptr));
+      max_dwtmp = std::max(max_dwtmp, (size_t)4 * 9 * x0.C * sizeof(float));
+      max_dA = std::max(max_dA, (size_t)B * S * S * x0.C * sizeof(float));
+      max_wt = std::max(max_wt, (size_t)x0.C * 9 * 4 * sizeof(float));
+      max_part = std::max(max_part, act_bwd_part_bytes(B, S * S, x0.C));
+      max_part = std::max(max_part, (size_t)B * chan_stats_slices(B, S * S, 4) * 4 * 2 * sizeof(double));
+      ConvParams g;
+      memset(&g, 0, sizeof(g));
+      g.C0 = 4; g.B = B; g.Hs = S; g.Ws = S; g.stride = 1; g.ksize = 3; g.Ho = S; g.Wo = S; g.Cout = x0.C;
+      max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
+    }
+  }
+  if (max_bscratch > P->t_scratch_bytes) {    // the forward's split-K region doubles as the backward's
+    off -= al(P->t_scratch_bytes);
+    P->t_scratch_bytes = max_bscratch;
+    off += al(max_bscratch);
+  }
+  P->t_dA_off = off; off += al(max_dA);
+  P->t_z_off = off; off += al(bld.max_z);
+  P->t_dq_off = off; off += al(bld.max_dq);
+  P->t_wt_off = off; off += al(max_wt);
+  P->t_slab_off = off; off += al(max_slab);
+  P->t_part_off = off; off += al(max_part);
+  P->t_gs_off = off; off += al((size_t)B * G * 2 * sizeof(float));
+  P->t_dfilm_off = off; off += al((size_t)B * P->F * sizeof(float));
+  P->t_xnoisy_off = off; off += al((size_t)B * (d.in_channel - cond_channels) * S * S * sizeof(float));
+  P->t_eps_off = off; off += al((size_t)B * P->out_ch * S * S * sizeof(float));
+  P->t_geps_off = off; off += al((size_t)B * S * S * 4 * sizeof(float));
+  P->t_inpad_off = off; off += al((size_t)B * S * S * 8 * sizeof(float));
+  P->t_dwtmp_off = off; off += al(4096 * sizeof(double)) + al(max_dwtmp);      // [loss partials | dw temp]
+  P->t_embscr_off = off; off += al((size_t)B * 13 * inner * sizeof(float));
+  P->t_ws_bytes = off;
+  P->train_batch = B;
+  P->train_cond = cond_channels;
   return SR3_OK;
 }
 
@@ -753,8 +840,9 @@ int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw
   }
   if (plan->d.variant == SR3_VARIANT_SR3 && !noise_level && !step_dev) { set_error("SR3 variant needs noise_level or step_dev"); return SR3_E_BADARG; }
   if (plan->d.variant == SR3_VARIANT_DDPM && !timestep && !step_dev) { set_error("DDPM variant needs timestep or step_dev"); return SR3_E_BADARG; }
-  return run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, level_table, step_dev, params,
-                     static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream));
+  return run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, level_table,
+                     step_dev, params, static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream),
+                     nullptr, nullptr);
 }
 
 int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
@@ -771,8 +859,8 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
   for (auto& e : ev) SR3_HIP(hipEventCreate(&e));
   for (auto& e : mid) SR3_HIP(hipEventCreate(&e));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  rc = run_forward(plan, x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr, nullptr, params,
-                   static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data(), mid.data());
+  rc = run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr,
+                   nullptr, params, static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data(), mid.data());
   if (!rc) {
     hipError_t e = hipEventSynchronize(ev[n]);
     if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");

@@ -1,0 +1,127 @@
+// Internal plan structures shared by plan.hip (inference driver) and train_plan.hip (training step).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sr3_mi355x.h"
+#include "sr3_common.h"
+
+namespace sr3 {
+
+// ---------------------------------------------------------------------------------------------
+// plan data
+// ---------------------------------------------------------------------------------------------
+struct Tensor {
+  size_t off = 0;       // byte offset in the workspace
+  size_t bytes = 0;
+  int C = 0, H = 0, W = 0;
+  size_t stat_off = 0;  // byte offset of the partial statistics [B][T][C][2] doubles (valid once stats_done)
+  int stat_T = 0;       // partials per image
+  bool stats_done = false;
+  bool valid = false;
+};
+
+struct ResLayer {
+  std::string name;     // e.g. "downs.1"
+  int cin, cout, skip;  // cin includes skip
+  bool attn;
+  int film_off;         // row offset in the FiLM table
+  size_t gn1_w, gn1_b, c1_w, c1_b, gn2_w, gn2_b, c2_w, c2_b, rc_w, rc_b;
+  bool has_rc;
+  size_t an_w, an_b, qkv_w, ao_w, ao_b;
+};
+
+struct Layer {
+  int kind;  // 0 conv_in, 1 res, 2 down, 3 up
+  std::string name;
+  int cin, cout;
+  size_t w, b;  // conv_in / down / up
+  ResLayer res;
+};
+
+enum OpKind { OP_MEMSET, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_ATTN, OP_CONV_OUT };
+
+struct Op {
+  OpKind kind;
+  // generic offsets (bytes into workspace unless noted)
+  size_t a = 0, b = 0, c = 0, d = 0, e = 0, f = 0, g = 0, h = 0;
+  size_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;   // float offsets into the parameter arena
+  int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
+  bool has_src1 = false, has_bias = false, has_film = false, has_res = false, has_res1 = false, has_ostat = false,
+       has_st1 = false, has_x2 = false, has_x21 = false;
+  size_t ss_rel = 0, mr_rel = 0;   // GroupNorm tables: offset inside the scale/shift region (0 in inference)
+  bool has_mr = false;
+  ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
+  int tile_cfg = 0, ksplit = 0;
+};
+
+struct Tap { std::string name; size_t off; int C, H, W; };
+
+// where the fixed regions of a compiled forward live inside the workspace
+struct Regions {
+  const std::vector<Op>* ops;
+  size_t stats_off, ss_off, mr_off, temb_off, film_off, scratch_off, scratch_bytes;
+};
+
+// one logical operation of the forward, recorded for the backward walk (train mode)
+enum RecKind { R_CONV_IN, R_CONV, R_ATTN, R_CONV_OUT };
+struct Rec {
+  int kind = R_CONV;
+  int x0 = -1, x1 = -1, out = -1, r0 = -1, r1 = -1, q0 = -1, q1 = -1;   // tensor handles
+  int ksize = 3, stride = 1, ups = 0, act = 0, film_row = -1;
+  size_t w = 0, bias = 0, qw = 0, qb = 0, gamma = 0, beta = 0;         // parameter arena offsets
+  bool has_bias = false, has_q = false;
+  size_t ss_off = 0, mr_off = 0;     // persistent GroupNorm tables of this conv's prologue (bytes in the workspace)
+  int qkv = -1, o = -1;              // attention
+};
+
+}  // namespace sr3
+
+using namespace sr3;
+
+struct sr3_plan {
+  sr3_unet_desc d;
+  std::vector<sr3_param_info> params;
+  std::map<std::string, int> pindex;
+  size_t param_floats = 0;
+  int F = 0;
+  size_t film_w = 0, film_b = 0;
+  size_t emb_w1 = 0, emb_b1 = 0, emb_w2 = 0, emb_b2 = 0;
+  std::vector<Layer> downs, mid, ups;
+  size_t fin_gn_w = 0, fin_gn_b = 0, fin_w = 0, fin_b = 0;
+  int fin_cin = 0, out_ch = 0;
+  // options
+  int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0;
+  // compiled forward
+  int built_batch = -1;
+  int built_cond = -1;
+  std::vector<Op> ops;
+  std::vector<Tap> taps;
+  size_t ws_bytes = 0;
+  size_t stats_off = 0, stats_bytes = 0, ss_off = 0, temb_off = 0, film_off = 0, scratch_off = 0, scratch_bytes = 0;
+  double flops = 0;
+  // ---- training step (train_plan.hip) ----
+  int train_batch = -1, train_cond = -1;
+  std::vector<Op> tops;              // forward ops in train mode (no buffer reuse, persistent GN tables)
+  std::vector<sr3::Tensor> ttens;    // tensor table of the train forward
+  std::vector<sr3::Rec> recs;
+  size_t t_act_bytes = 0;            // activations; gradients mirror them at +t_act_bytes
+  size_t t_stats_off = 0, t_gn_off = 0, t_temb_off = 0, t_film_off = 0, t_scratch_off = 0, t_scratch_bytes = 0;
+  size_t t_dA_off = 0, t_z_off = 0, t_dq_off = 0, t_wt_off = 0, t_slab_off = 0, t_part_off = 0, t_gs_off = 0;
+  size_t t_dfilm_off = 0, t_misc_off = 0, t_xnoisy_off = 0, t_eps_off = 0, t_geps_off = 0, t_inpad_off = 0, t_dwtmp_off = 0;
+  size_t t_ws_bytes = 0, t_embscr_off = 0;
+  int t_final_x = -1;                // tensor handle feeding the output Block
+  size_t t_final_ss = 0, t_final_mr = 0;
+  int t_conv_in_out = -1;
+};
+
+
+namespace sr3 {
+struct Builder;
+Regions infer_regions(const sr3_plan* P);
+int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
+                const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
+                const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid);
+int build_train(sr3_plan* P, int B, int cond_channels);
+}  // namespace sr3

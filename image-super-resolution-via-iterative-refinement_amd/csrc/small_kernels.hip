@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ s
                                                      const double* __restrict__ st1, int C1, int T1, int HW,
                                                      int groups, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps,
-                                                     float* __restrict__ ss) {
+                                                     float* __restrict__ ss, float* __restrict__ mr) {
   const int C = C0 + C1;
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int cpg = C / groups;
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ s
   double var = s2 / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (mr && lane == 0) { mr[((size_t)b * groups + g) * 2] = (float)mean; mr[((size_t)b * groups + g) * 2 + 1] = rstd; }
   for (int k = lane; k < cpg; k += 64) {
     const int c = g * cpg + k;
     const float sc = rstd * gamma[c];
@@ -135,11 +136,11 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const double* __restrict__ s
 }
 
 int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW, int groups,
-                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st) {
+                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st, float* mr) {
   const int C = C0 + C1;
   if (groups <= 0 || C % groups) { set_error("gn_finalize: C=%d not divisible by groups=%d", C, groups); return SR3_E_BADARG; }
   hipLaunchKernelGGL(k_gn_finalize, dim3(B * groups), dim3(64), 0, st, stat0, C0, T0, stat1, C1, T1, HW, groups,
-                     gamma, beta, eps, ss);
+                     gamma, beta, eps, ss, mr);
   SR3_LAUNCH_CHECK("k_gn_finalize");
   return SR3_OK;
 }

@@ -93,7 +93,7 @@ int chan_stats_slices(int B, int HW, int C);
 int chan_stats(const float* x, int B, int HW, int C, double* stat, hipStream_t st);
 // GroupNorm fold: partial stats of up to two concat sources + gamma/beta -> ss[B][C0+C1][2]
 int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1, int T1, int B, int HW, int groups,
-                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st);
+                const float* gamma, const float* beta, float eps, float* ss, hipStream_t st, float* mr = nullptr);
 // partials per image the halo conv writes into ConvParams::ostat for this geometry
 int halo_stats_slices(const HaloGeom& g);
 // first conv of the UNet: NCHW inputs (virtual concat of a: Ca, b: Cb channels), 3x3 pad 1,

@@ -1,0 +1,52 @@
+// Internal declarations of the training-step kernels (train_kernels.hip, wgrad.hip, attention_bwd.hip).
+#pragma once
+#include "sr3_common.h"
+
+namespace sr3 {
+
+// GroupNorm(+SiLU) backward over the virtual concat (x0|x1): dA (grad w.r.t. the activated input) is
+// overwritten with du, partial sums go to `part`, group sums to gs[B][G][2], parameter gradients to
+// dgamma/dbeta[C], and dx0/dx1 (+=) receive the input gradient.  mr[B][G][2] = (mean, rstd).
+int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
+            int groups, int act, const float* gamma, double* part, float* gs, float* dgamma, float* dbeta, float* dx0,
+            float* dx1, hipStream_t st);
+size_t act_bwd_part_bytes(int B, int HW, int C);
+int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st);
+int zero_insert(const float* g, int B, int Ho, int Wo, int C, float* z, hipStream_t st);
+int w_flip_transpose(const float* w, int Cout, int taps, int Cin, int CoutP, float* wt, hipStream_t st);
+int colsums(const float* g, int B, int HW, int C, double* part, float* dbias, float* dfilm, int film_stride,
+            hipStream_t st);
+int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, float scale, float* g_nhwc,
+                 double* loss_part, float* loss_out, hipStream_t st);
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
+              hipStream_t st);
+int nchw_to_nhwc_pad(const float* a, int Ca, const float* b, int Cb, int B, int HW, int CP, float* out, hipStream_t st);
+
+// Weight gradient of a conv (wgrad.hip): dw[n][tap][c] = sum_m dy[m][n] * a_tap[m][c], a = prologue(x0|x1)
+// recomputed on the fly (same ConvParams geometry as the forward; p.out / p.w unused).
+// `slabs` holds the per-pixel-split partial results; dw is overwritten.
+struct WgradParams {
+  ConvParams c;        // forward geometry + src0/src1/ss/act (+ ups/stride/ksize)
+  const float* dy;     // [B,Ho,Wo,Cout]
+  float* dw;           // [Cout][taps][Cin]
+  float* slabs;        // [msplit][Cout][taps][Cin]
+  int msplit;
+};
+size_t wgrad_slab_bytes(const ConvParams& c, int* msplit_out);
+int conv_wgrad(const WgradParams& p, hipStream_t st);
+
+// Attention backward (attention_bwd.hip): qkv [B][N][3C], dout [B][N][C] -> dqkv [B][N][3C] (overwritten)
+int attention_backward(const float* qkv, const float* dout, int B, int N, int C, float* dqkv, hipStream_t st);
+
+// Embedding / FiLM backward (small): see train_small.hip
+struct EmbedBwdParams {
+  int variant, B, inner, F;
+  const float* level; const int64_t* tstep; const float* freq;
+  const float* w1; const float* b1; const float* w2; const float* b2; const float* wf;
+  const float* dfilm;     // [B][F]
+  float* dw1; float* db1; float* dw2; float* db2; float* dwf; float* dbf;
+  float* scratch;         // >= B * (8 * inner) floats
+};
+int embed_backward(const EmbedBwdParams& p, hipStream_t st);
+
+}  // namespace sr3

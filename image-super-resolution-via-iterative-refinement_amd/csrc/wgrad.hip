@@ -1,0 +1,237 @@
+// Weight gradient of every conv of the UNet (autograd of nn.Conv2d in the reference's
+// `l_pix.backward()`, model/model.py:54) as a GEMM over pixels on v_mfma_f32_32x32x2_f32:
+//     dw[n][tap][c] = sum_{m = (b, oh, ow)} dy[m][n] * a[b, oh*s + r - pad, ow*s + q - pad, c]
+// with a = the conv's activated input (GroupNorm affine + SiLU of the virtual concat x0|x1, nearest
+// x2 upsample folded into the address), recomputed on the fly instead of being stored by the forward.
+// Both operands are pixel-major ([m][channels], the natural NHWC order), so a k-step reads its
+// fragments with conflict-free ds_read_b32 (lanes along channels).  Workgroup tile TN x TC of one
+// filter tap; pixels are walked in chunks of 32, register-prefetched and double-buffered; the pixel
+// range is split over gridDim.z and the partial slabs are summed by a deterministic reduce kernel.
+#include "sr3_common.h"
+#include "train.h"
+
+namespace sr3 {
+
+__device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+
+template <int TN, int TC>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const float* __restrict__ dy,
+                                                        float* __restrict__ slabs, int chunks_per_split) {
+  constexpr int LDN = TN + 4, LDC = TC + 4;
+  constexpr int YR = TN / 32, AR = TC / 32;      // float4 loads per thread per chunk (TN/4 * 32 / 256)
+  constexpr int WN = TN / 2, WC = TC / 2;
+  constexpr int MI = WN / 32, NI = WC / 32;
+  constexpr int STAGE = 32 * (LDN + LDC);
+  extern __shared__ f32x4 smem_v[];
+  float* smem = reinterpret_cast<float*>(smem_v);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cin = p.C0 + p.C1;
+  const int taps = p.ksize * p.ksize;
+  const int pad = p.ksize / 2;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
+  const int tiles_c = (Cin + TC - 1) / TC;
+  const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_n * tiles_c;
+  const int tap = blockIdx.y;
+  const int fr = tap / p.ksize, fs = tap - fr * p.ksize;
+  const int nchunks = (M + 31) / 32;
+  const int ch0 = blockIdx.z * chunks_per_split;
+  const int ch1 = min(nchunks, ch0 + chunks_per_split);
+
+  const int lq = tid & 31, lpx = tid >> 5;        // loader: channel quad, pixel row (0..7) + 8 i
+  f32x4 ry[4], ra[4], sa[4], sb[4];
+  bool yok[4], aok[4];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](int chunk) {
+    const int n = tile_n * TN + lq * 4;
+    const int c = tile_c * TC + lq * 4;
+    const bool nv = (lq * 4 < TN) && n < p.Cout;
+    const bool cv = (lq * 4 < TC) && c < Cin;
+    const int ce = cv ? c : 0;
+    const bool second = ce >= p.C0;
+    const float* sp = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = chunk * 32 + lpx + 8 * i;
+      const bool mv = m < M;
+      const int me = mv ? m : 0;
+      const int b = me / HoWo;
+      const int rem = me - b * HoWo;
+      const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      yok[i] = mv && nv;
+      ry[i] = *reinterpret_cast<const f32x4*>(dy + (yok[i] ? me * p.Cout + n : 0));
+      const int ih = oh * p.stride + fr - pad, iw = ow * p.stride + fs - pad;
+      const bool ok = mv && cv && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+      aok[i] = ok;
+      const int pix = (b * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+      ra[i] = *reinterpret_cast<const f32x4*>(sp + (ok ? pix * sC + cs : 0));
+      if (p.act != 0) {
+        const float* q = p.ss + (b * Cin + ce) * 2;
+        sa[i] = *reinterpret_cast<const f32x4*>(q);
+        sb[i] = *reinterpret_cast<const f32x4*>(q + 4);
+      }
+    }
+  };
+  auto store = [&](int st) {
+    float* Ys = smem + st * STAGE;
+    float* As = Ys + 32 * LDN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = lpx + 8 * i;
+      if (lq * 4 < TN) *reinterpret_cast<f32x4*>(&Ys[px * LDN + lq * 4]) = yok[i] ? ry[i] : zero;
+      if (lq * 4 < TC) {
+        f32x4 v = ra[i];
+        if (p.act != 0) {
+          v.x = fmaf(v.x, sa[i].x, sa[i].y);
+          v.y = fmaf(v.y, sa[i].z, sa[i].w);
+          v.z = fmaf(v.z, sb[i].x, sb[i].y);
+          v.w = fmaf(v.w, sb[i].z, sb[i].w);
+          if (p.act == 2) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
+        }
+        *reinterpret_cast<f32x4*>(&As[px * LDC + lq * 4]) = aok[i] ? v : zero;
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave_n = wave >> 1, wave_c = wave & 1;
+  const int ncol = wave_n * WN + (lane & 31);
+  const int ccol = wave_c * WC + (lane & 31);
+  const int khalf = lane >> 5;
+
+  if (ch0 < ch1) {
+    load(ch0);
+    store(0);
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+      const int cur = (ch - ch0) & 1;
+      const bool more = ch + 1 < ch1;
+      if (more) load(ch + 1);
+      const float* Ys = smem + cur * STAGE;
+      const float* As = Ys + 32 * LDN;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + khalf;
+        float a[MI], bq[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = Ys[row * LDN + ncol + 32 * i];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bq[j] = As[row * LDC + ccol + 32 * j];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+      }
+      if (more) store(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* dst = slabs + (size_t)blockIdx.z * p.Cout * taps * Cin;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int c = tile_c * TC + wave_c * WC + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = tile_n * TN + wave_n * WN + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.Cout && c < Cin) dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int msplit, size_t n4,
+                                                       float* __restrict__ dw) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + i * 4);
+    for (int s = 1; s < msplit; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((size_t)s * n4 + i) * 4);
+    *reinterpret_cast<f32x4*>(dw + i * 4) = v;
+  }
+}
+
+namespace {
+inline int cdivw(int a, int b) { return (a + b - 1) / b; }
+void wgrad_geometry(const ConvParams& c, int* tn, int* tc, int* msplit, int* cps) {
+  const int Cin = c.C0 + c.C1;
+  const int taps = c.ksize * c.ksize;
+  const bool small = c.Cout <= 64 || Cin <= 64;
+  *tn = small ? 64 : 128;
+  *tc = small ? 64 : 128;
+  const long tiles = (long)cdivw(c.Cout, *tn) * cdivw(Cin, *tc) * taps;
+  const int nchunks = cdivw(c.B * c.Ho * c.Wo, 32);
+  long ms = (1024 + tiles - 1) / tiles;
+  const long cap = nchunks / 4 > 1 ? nchunks / 4 : 1;
+  if (ms > cap) ms = cap;
+  if (ms < 1) ms = 1;
+  int per = cdivw(nchunks, (int)ms);
+  ms = cdivw(nchunks, per);
+  *msplit = (int)ms;
+  *cps = per;
+}
+
+template <int TN, int TC>
+int launch_wgrad(const WgradParams& p, int msplit, int cps, hipStream_t st) {
+  constexpr int smem = 2 * 32 * (TN + 4 + TC + 4) * 4;
+  static bool attr_set = false;
+  auto kern = k_conv_wgrad<TN, TC>;
+  if (!attr_set) {
+    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int Cin = p.c.C0 + p.c.C1;
+  const int taps = p.c.ksize * p.c.ksize;
+  dim3 grid(cdivw(p.c.Cout, TN) * cdivw(Cin, TC), taps, msplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p.c, p.dy, msplit > 1 ? p.slabs : p.dw, cps);
+  SR3_LAUNCH_CHECK("k_conv_wgrad");
+  return SR3_OK;
+}
+}  // namespace
+
+size_t wgrad_slab_bytes(const ConvParams& c, int* msplit_out) {
+  int tn, tc, ms, cps;
+  wgrad_geometry(c, &tn, &tc, &ms, &cps);
+  if (msplit_out) *msplit_out = ms;
+  if (ms <= 1) return 0;
+  return (size_t)ms * c.Cout * c.ksize * c.ksize * (c.C0 + c.C1) * sizeof(float);
+}
+
+int conv_wgrad(const WgradParams& p, hipStream_t st) {
+  const ConvParams& c = p.c;
+  const int Cin = c.C0 + c.C1;
+  if ((c.C0 & 3) || (c.C1 & 3) || (c.Cout & 3)) { set_error("wgrad: channel counts must be multiples of 4"); return SR3_E_UNSUPPORTED; }
+  if ((double)c.B * c.Ho * c.Wo * c.Cout >= 2147483647.0 || (double)c.B * c.Hs * c.Ws * (c.C0 > c.C1 ? c.C0 : c.C1) >= 2147483647.0) {
+    set_error("wgrad: tensor exceeds 2^31 elements");
+    return SR3_E_UNSUPPORTED;
+  }
+  if (c.act != 0 && !c.ss) { set_error("wgrad: act needs ss"); return SR3_E_BADARG; }
+  int tn, tc, ms, cps;
+  wgrad_geometry(c, &tn, &tc, &ms, &cps);
+  if (ms != p.msplit) { set_error("wgrad: msplit mismatch (%d vs %d)", ms, p.msplit); return SR3_E_BADARG; }
+  if (ms > 1 && !p.slabs) { set_error("wgrad: slabs required"); return SR3_E_BADARG; }
+  int rc = tn == 128 ? launch_wgrad<128, 128>(p, ms, cps, st) : launch_wgrad<64, 64>(p, ms, cps, st);
+  if (rc) return rc;
+  if (ms > 1) {
+    const size_t n4 = (size_t)c.Cout * c.ksize * c.ksize * Cin / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)blocks), dim3(256), 0, st, p.slabs, ms, n4, p.dw);
+    SR3_LAUNCH_CHECK("k_wgrad_reduce");
+  }
+  return SR3_OK;
+}
+
+}  // namespace sr3

@@ -44,10 +44,11 @@ class DDPM(BaseModel):
 
     def optimize_parameters(self):
         self.optG.zero_grad()
+        # forward + backward run inside the engine; the gradients already carry the 1/(b*c*h*w) factor
         l_pix = self.netG(self.data)
         b, c, h, w = self.data['HR'].shape
         l_pix = l_pix.sum() / int(b * c * h * w)
-        self.optG.backward_and_step(self.netG, scale=1.0 / int(b * c * h * w))
+        self.optG.step()
         self.log_dict['l_pix'] = l_pix.item()
 
     def test(self, continous=False):

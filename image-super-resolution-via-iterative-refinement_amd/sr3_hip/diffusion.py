@@ -292,8 +292,36 @@ class EngineDiffusion(nn.Module):
         t = t_or_gamma.long()
         return self._q_sample_coef(x_start, self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t], noise)
 
-    def p_losses(self, x_in, noise=None):
-        raise NotImplementedError('training step (p_losses backward + Adam) kernels are not built yet in this round')
+    def p_losses(self, x_in, noise=None, gamma=None, t=None):
+        """sr3 diffusion.py:221-246 / ddpm :278-294.  Draws (t, gamma, z) exactly as the reference does
+        (numpy global RNG for the SR3 level, torch RNG for z / the DDPM timesteps) unless injected, then
+        runs forward + backward in one engine call: returns the sum-reduced L1 loss (0-dim device tensor)
+        and leaves d(loss / (b c h w)) / d params in `denoise_fn.grad_arena` for the optimizer."""
+        x_start = x_in['HR'].contiguous()
+        b, c, h, w = x_start.shape
+        dev = x_start.device
+        if dev.type != 'cuda':
+            raise L.Sr3Error('training needs the model on a GPU; there is no CPU fallback')
+        un = self.denoise_fn
+        level = tstep = None
+        if self.variant == 'sr3':
+            if gamma is None:
+                tt = np.random.randint(1, self.num_timesteps + 1) if t is None else int(t)
+                gamma = torch.FloatTensor(np.random.uniform(self.sqrt_alphas_cumprod_prev[tt - 1],
+                                                            self.sqrt_alphas_cumprod_prev[tt], size=b))
+            g = gamma.reshape(-1).float().to(dev)
+            ca, cb = g, (1 - g ** 2).sqrt()
+            level = g
+        else:
+            if t is None:
+                t = torch.randint(0, self.num_timesteps, (b,), device=dev).long()
+            tstep = t.long().to(dev)
+            ca, cb = self.sqrt_alphas_cumprod[tstep], self.sqrt_one_minus_alphas_cumprod[tstep]
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        cond = x_in['SR'].contiguous() if self.conditional else None
+        return un.train_step(x_start, cond, noise.contiguous(), ca.contiguous(), cb.contiguous(), level, tstep,
+                             grad_scale=1.0 / float(b * c * h * w))
 
     def forward(self, x, *args, **kwargs):
         return self.p_losses(x, *args, **kwargs)

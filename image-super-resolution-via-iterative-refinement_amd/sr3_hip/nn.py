@@ -135,6 +135,41 @@ class EngineUNet(nn.Module):
         return E.unet_forward(self.plan, self.arena.data, self.freq, self._ws, x, cond=cond,
                               level_table=level_table, step_dev=step_dev, out=out, **kw)
 
+    # ---- training step (forward + backward inside the engine) ------------------------------------
+    def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale):
+        import ctypes as C
+        if self.dropout != 0 and self.training:
+            if not getattr(self, '_warned_dropout', False):
+                import warnings
+                warnings.warn('engine training step runs without dropout (p=%g ignored in this round)' % self.dropout)
+                self._warned_dropout = True
+        dev = hr.device
+        B = hr.shape[0]
+        plan = self.plan
+        cc = 0 if cond is None else cond.shape[1]
+        need = int(plan.lib.sr3_train_workspace_bytes(plan.handle, B, cc))
+        if need == 0:
+            raise L.Sr3Error('sr3_train_workspace_bytes failed: %s' % (plan.lib.sr3_last_error() or b'').decode())
+        ws = getattr(self, '_train_ws', None)
+        if ws is None or ws.numel() < need + 256 or ws.device != dev:
+            ws = self._train_ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        wsv = ws[off:off + need]
+        if getattr(self, 'grad_arena', None) is None or self.grad_arena.device != dev:
+            self.grad_arena = torch.zeros_like(self.arena.data)
+        loss = torch.zeros(1, device=dev)
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        L.check(plan.lib.sr3_train_step(plan.handle, L.ptr(hr), L.ptr(cond), cc, L.ptr(z), L.ptr(ca), L.ptr(cb),
+                                        L.ptr(level), L.ptr(tstep), L.ptr(self.freq), L.ptr(self.arena.data),
+                                        L.ptr(self.grad_arena), L.ptr(wsv), need, L.ptr(loss), C.c_float(grad_scale), B,
+                                        stream))
+        return loss[0]
+
+    def named_gradients(self):
+        """(reference key, gradient view in the reference shape) after a train_step."""
+        for e in self.plan.table:
+            yield e['name'], self.plan.view(self.grad_arena, e)
+
     def extra_repr(self):
         d = self.plan.desc
         return 'variant=%s, in=%d, out=%d, inner=%d, groups=%d, mults=%s, attn_res=%s, res_blocks=%d, image=%d, ' \

@@ -136,6 +136,30 @@ int sr3_step_decrement(int* step_dev, void* stream);
 int sr3_q_sample(const float* x0, const float* z, const float* ca, const float* cb, int batch,
                  int elems_per_image, float* out, void* stream);
 
+/* ---- training step ------------------------------------------------------------------------- */
+
+/* Workspace of sr3_train_step (activations kept for the backward, their gradient mirror, scratch). */
+size_t sr3_train_workspace_bytes(sr3_plan* plan, int batch, int cond_channels);
+
+/* One training step up to the gradients: `l_pix = netG(data); l_pix.backward()` of
+ * DDPM.optimize_parameters (model/model.py:50-54) over GaussianDiffusion.p_losses
+ * (model/sr3_modules/diffusion.py:221-246, model/ddpm_modules/diffusion.py:278-294):
+ *   x_noisy = q_ca[b] * hr + q_cb[b] * z ; eps = UNet(cat(cond, x_noisy), level) ;
+ *   *loss_sum_out = sum |z - eps| ; grads = d(grad_scale * loss_sum) / d params
+ * (grad_scale = 1 / (b*c*h*w), model.py:52-53).  The random draws (t / gamma, z) are made by the caller
+ * (torch / numpy RNG, as in the reference) and passed in.  `grads` has the layout of the parameter
+ * arena and is overwritten.  Dropout is not applied (p = 0). */
+int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw, int cond_channels,
+                   const float* z_nchw, const float* q_ca, const float* q_cb, const float* noise_level,
+                   const int64_t* timestep, const float* freq, const float* params, float* grads,
+                   void* workspace, size_t workspace_bytes, float* loss_sum_out, float grad_scale, int batch,
+                   void* stream);
+
+/* torch.optim.Adam step (model/model.py:39-40,55; defaults beta 0.9/0.999, eps 1e-8, no weight decay)
+ * fused over the whole arena; `step` is the 1-based step count for the bias corrections. */
+int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                  float beta1, float beta2, float eps, int step, void* stream);
+
 /* ---- per-op entry points (unit tests, micro-benchmarks) ------------------------------------ */
 
 /* Block / Conv2d / Downsample / Upsample / res_conv / qkv / out as one implicit-GEMM call:

@@ -1,0 +1,80 @@
+"""Training step parity: engine forward+backward+Adam vs the reference's autograd step recorded in
+tests/golden (loss, every parameter gradient, weights after one Adam step; dropout 0, injected t / gamma / z).
+Tolerances: loss rel 1e-5, gradients normwise rel 1e-4, post-Adam weights see below."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import DESCS, CONDITIONAL, load_golden, opt_for      # noqa: E402
+import gpu_util as G                                             # noqa: E402
+
+
+def build_train(name):
+    import model as Model
+    opt = opt_for(name, phase='train', gpu=True)
+    m = Model.create_model(opt)
+    g, sd = load_golden(name)
+    m.netG.load_state_dict(sd, strict=True)
+    return m, g, sd
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_loss_and_gradients_match_reference_autograd(name):
+    m, g, sd = build_train(name)
+    d = G.dev()
+    data = {'HR': torch.from_numpy(g['loop/hr']).to(d), 'SR': torch.from_numpy(g['loop/sr']).to(d)}
+    z = torch.from_numpy(g['train/z']).to(d)
+    if DESCS[name]['variant'] == 'sr3':
+        loss = m.netG.p_losses(data, noise=z, gamma=torch.from_numpy(g['train/gamma']))
+    else:
+        loss = m.netG.p_losses(data, noise=z, t=torch.from_numpy(g['train/t']).to(d))
+    torch.cuda.synchronize()
+    ref_loss = float(g['train/loss_sum'])
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss), (float(loss), ref_loss)
+    worst = []
+    for key, grad in m.netG.denoise_fn.named_gradients():
+        ref = torch.from_numpy(g['grad/denoise_fn.' + key])
+        got = grad.cpu()
+        assert got.shape == ref.shape, key
+        num = (got - ref).norm().item()
+        den = max(ref.norm().item(), 1e-7)
+        worst.append((num / den, key, den))
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[0] > 1e-4 and w[2] > 1e-6]
+    assert not bad, 'gradient mismatch (rel err, key, |ref|): %s' % bad[:8]
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_optimize_parameters_one_adam_step(name):
+    """feed_data -> optimize_parameters (RNG draws patched to the recorded ones) -> weights after Adam."""
+    m, g, sd = build_train(name)
+    d = G.dev()
+    netG = m.netG
+    z = torch.from_numpy(g['train/z']).to(d)
+    orig = netG.p_losses
+    if DESCS[name]['variant'] == 'sr3':
+        netG.p_losses = lambda x_in, noise=None: orig(x_in, noise=z, gamma=torch.from_numpy(g['train/gamma']))
+    else:
+        netG.p_losses = lambda x_in, noise=None: orig(x_in, noise=z, t=torch.from_numpy(g['train/t']).to(d))
+    m.feed_data({'HR': torch.from_numpy(g['loop/hr']), 'SR': torch.from_numpy(g['loop/sr'])})
+    m.optimize_parameters()
+    assert abs(m.get_current_log()['l_pix'] - float(g['train/l_pix'])) <= 1e-5 * abs(float(g['train/l_pix']))
+    out = netG.state_dict()
+    # Adam's first step moves every weight by ~lr * sign(g): compare the *update*; entries whose
+    # reference gradient is ~0 have an ill-conditioned sign and are excluded
+    tot = bad = 0
+    for k, ref_new in g.items():
+        if not k.startswith('adam1/'):
+            continue
+        key = k[len('adam1/'):]
+        ref_new = torch.from_numpy(ref_new)
+        old = sd[key]
+        grad = torch.from_numpy(g['grad/' + key])
+        mask = grad.abs() > 1e-6 * max(grad.abs().max().item(), 1e-12) + 1e-9
+        upd = (out[key].cpu() - old)[mask]
+        ref_upd = (ref_new - old)[mask]
+        tot += mask.sum().item()
+        bad += ((upd - ref_upd).abs() > 2e-6).sum().item()
+    assert tot > 1000 and bad <= 1e-4 * tot, (bad, tot)

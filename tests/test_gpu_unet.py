@@ -129,8 +129,6 @@ def test_api_surface_test_and_visuals():
     assert set(vis.keys()) == {'SR', 'INF', 'HR', 'LR'} and vis['SR'].device.type == 'cpu'
     m.test(continous=False)
     assert tuple(m.SR.shape) == (3, 16, 16)       # ret_img[-1]: last image of the batch only
-    with pytest.raises(NotImplementedError):
-        m.netG({'HR': data['HR'], 'SR': data['SR']})
 
 
 def test_engine_refuses_cpu():
