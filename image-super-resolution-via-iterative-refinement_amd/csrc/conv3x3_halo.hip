@@ -95,12 +95,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   bool hvalid = false;      // channel quad of the staged chunk is inside Cin
 
   int cur_act = 0;          // prologue of the staged chunk (segment 2 has none)
+  int cur_c = 0;            // first channel of this thread's quad in the staged chunk
   auto load_halo = [&](auto seg2_tag, int chunk) {
     constexpr bool seg2 = decltype(seg2_tag)::value;
     const int CinS = seg2 ? Cin2 : Cin;
     const int C0S = seg2 ? p.x2_C0 : p.C0;
     const int c = chunk * BK + kq * 4;
     hvalid = c < CinS;
+    cur_c = c;
     cur_act = seg2 ? 0 : p.act;
     const int ce = hvalid ? c : 0;
     const bool second = ce >= C0S;
@@ -138,6 +140,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
           v.z = fmaf(v.z, sb.x, sb.y);
           v.w = fmaf(v.w, sb.z, sb.w);
           if (cur_act == 2) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
+          if (p.drop_thresh != 0) {      // segment 1 only (cur_act != 0), single source => linear NHWC index
+            const unsigned i0 = (unsigned)(hpix[j] * p.C0 + cur_c);
+            v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
+            v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
+            v.z *= drop_mask(p.drop_seed, i0 + 2, p.drop_thresh, p.drop_scale);
+            v.w *= drop_mask(p.drop_seed, i0 + 3, p.drop_thresh, p.drop_scale);
+          }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
         *reinterpret_cast<f32x4*>(&halo[hp * LDK + kq * 4]) = v;

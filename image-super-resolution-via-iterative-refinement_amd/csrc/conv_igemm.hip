@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
 
   f32x4 ra[AR], rw[BR], ssa[AR], ssb[AR];
   bool aok[AR], wok[BR];
+  int aoff[AR];             // element offset of the staged quad (dropout mask index)
   int ss_chunk = -1;
 
   // Every global load below is UNCONDITIONAL (out-of-range lanes read element 0 of the same
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
       aok[i] = ok;
       const int pix = (rb[i] * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
       const int off = ok ? pix * sC + cs : 0;
+      aoff[i] = off;
       ra[i] = *reinterpret_cast<const f32x4*>(sp + off);
     }
 #pragma unroll
@@ -133,6 +135,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
         v.z = fmaf(v.z, ssb[i].x, ssb[i].y);
         v.w = fmaf(v.w, ssb[i].z, ssb[i].w);
         if (p.act == 2) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        if (p.drop_thresh != 0) {
+          const unsigned i0 = (unsigned)aoff[i];
+          v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
+          v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
+          v.z *= drop_mask(p.drop_seed, i0 + 2, p.drop_thresh, p.drop_scale);
+          v.w *= drop_mask(p.drop_seed, i0 + 3, p.drop_thresh, p.drop_scale);
+        }
       }
       v = aok[i] ? v : zero;     // zero padding is applied AFTER the activation, as the reference does
       *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
@@ -391,6 +400,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   if (p.ksize != 1 && p.ksize != 3) { set_error("conv: ksize %d unsupported", p.ksize); return SR3_E_UNSUPPORTED; }
   if (p.stride != 1 && p.stride != 2) { set_error("conv: stride %d unsupported", p.stride); return SR3_E_UNSUPPORTED; }
   if (p.act != 0 && !p.ss) { set_error("conv: act needs ss"); return SR3_E_BADARG; }
+  if (p.drop_thresh != 0 && (p.C1 != 0 || p.ups != 0 || p.act == 0)) { set_error("conv: dropout needs a single-source, non-upsampled, activated input"); return SR3_E_UNSUPPORTED; }
   if (p.C1 > 0 && !p.src1) { set_error("conv: C1 > 0 needs src1"); return SR3_E_BADARG; }
   if (p.res0 && p.RC0 + p.RC1 != p.Cout) { set_error("conv: residual channels %d+%d != Cout %d", p.RC0, p.RC1, p.Cout); return SR3_E_BADARG; }
   const int pad = p.ksize / 2;

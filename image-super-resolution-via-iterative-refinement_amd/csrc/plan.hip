@@ -347,7 +347,7 @@ struct Builder {
   // generic conv over the virtual concat (x0|x1); residual is the concat view (r0|r1)
   int conv(int x0, int x1, int Cout, int ksize, int stride, int ups, int act_mode, size_t w, bool has_bias,
            size_t bias, int film_row, int r0, int r1, bool want_stats, int q0 = -1, int q1 = -1, size_t qw = 0,
-           size_t qb = 0) {
+           size_t qb = 0, int drop_key = -1) {
     const int C0 = T[x0].C, C1 = x1 >= 0 ? T[x1].C : 0;
     const int Hi = T[x0].H << ups, Wi = T[x0].W << ups;
     const int pad = ksize / 2;
@@ -370,6 +370,7 @@ struct Builder {
     o.e = T[out].off;
     o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
     o.ss_rel = act_mode ? cur_ss : 0;
+    o.has_drop = train && drop_key >= 0; o.drop_key = (unsigned)(drop_key >= 0 ? drop_key : 0);
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (train) {
       Rec r;
@@ -377,6 +378,7 @@ struct Builder {
       r.ksize = ksize; r.stride = stride; r.ups = ups; r.act = act_mode; r.film_row = film_row;
       r.w = w; r.bias = bias; r.has_bias = has_bias; r.qw = qw; r.qb = qb; r.has_q = q0 >= 0;
       r.gamma = cur_gamma; r.beta = cur_beta; r.ss_off = cur_ss; r.mr_off = cur_mr;
+      r.has_drop = o.has_drop; r.drop_key = o.drop_key;
       P->recs.push_back(r);
       // scratch the backward of this conv needs
       const size_t cin = (size_t)(C0 + C1);
@@ -431,13 +433,13 @@ struct Builder {
     fold(h1, -1, R.gn2_w, R.gn2_b);
     int out;
     if (R.has_rc && can_fuse_x2(h1, R.cout)) {
-      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, -1, -1, true, x0, x1, R.rc_w, R.rc_b);
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, -1, -1, true, x0, x1, R.rc_w, R.rc_b, R.film_off);
     } else if (R.has_rc) {
       const int r = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
-      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, r, -1, true);
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, r, -1, true, -1, -1, 0, 0, R.film_off);
       drop(r);
     } else {
-      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, x0, x1, true);
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, x0, x1, true, -1, -1, 0, 0, R.film_off);
     }
     drop(h1);
     if (R.attn) {
@@ -567,7 +569,7 @@ Regions infer_regions(const sr3_plan* P) {
 int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
                 const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st,
-                hipEvent_t* ev, hipEvent_t* mid) {
+                hipEvent_t* ev, hipEvent_t* mid, const DropCfg* drop) {
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
   float* film = reinterpret_cast<float*>(ws + R.film_off);
@@ -624,6 +626,9 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         c.res1 = o.has_res1 ? reinterpret_cast<const float*>(ws + o.d) : nullptr;
         c.out = reinterpret_cast<float*>(ws + o.e);
         c.ostat = o.has_ostat ? reinterpret_cast<double*>(ws + R.stats_off + o.f) : nullptr;
+        if (drop && o.has_drop && drop->thresh != 0) {
+          c.drop_seed = drop_layer_seed(drop->seed, o.drop_key); c.drop_thresh = drop->thresh; c.drop_scale = drop->scale;
+        }
         if (o.has_x2) {
           c.x2_src0 = reinterpret_cast<const float*>(ws + o.g);
           c.x2_src1 = o.has_x21 ? reinterpret_cast<const float*>(ws + o.h) : nullptr;
@@ -733,6 +738,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
     off += al(max_bscratch);
   }
   P->t_dA_off = off; off += al(max_dA);
+  P->t_a_off = off; off += al(max_dA);       // materialised activated input of the weight-gradient GEMM
   P->t_z_off = off; off += al(bld.max_z);
   P->t_dq_off = off; off += al(bld.max_dq);
   P->t_wt_off = off; off += al(max_wt);

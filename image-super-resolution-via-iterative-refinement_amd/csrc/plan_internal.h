@@ -51,7 +51,8 @@ struct Op {
   bool has_src1 = false, has_bias = false, has_film = false, has_res = false, has_res1 = false, has_ostat = false,
        has_st1 = false, has_x2 = false, has_x21 = false;
   size_t ss_rel = 0, mr_rel = 0;   // GroupNorm tables: offset inside the scale/shift region (0 in inference)
-  bool has_mr = false;
+  bool has_mr = false, has_drop = false;
+  unsigned drop_key = 0;
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
 };
@@ -74,7 +75,12 @@ struct Rec {
   bool has_bias = false, has_q = false;
   size_t ss_off = 0, mr_off = 0;     // persistent GroupNorm tables of this conv's prologue (bytes in the workspace)
   int qkv = -1, o = -1;              // attention
+  bool has_drop = false;             // block2 conv: train-mode dropout on its activated input
+  unsigned drop_key = 0;
 };
+
+struct DropCfg { unsigned seed, thresh; float scale; };
+inline unsigned drop_layer_seed(unsigned seed, unsigned key) { return seed + (key + 1u) * 0x632BE5ABu; }
 
 }  // namespace sr3
 
@@ -110,7 +116,7 @@ struct sr3_plan {
   size_t t_stats_off = 0, t_gn_off = 0, t_temb_off = 0, t_film_off = 0, t_scratch_off = 0, t_scratch_bytes = 0;
   size_t t_dA_off = 0, t_z_off = 0, t_dq_off = 0, t_wt_off = 0, t_slab_off = 0, t_part_off = 0, t_gs_off = 0;
   size_t t_dfilm_off = 0, t_misc_off = 0, t_xnoisy_off = 0, t_eps_off = 0, t_geps_off = 0, t_inpad_off = 0, t_dwtmp_off = 0;
-  size_t t_ws_bytes = 0, t_embscr_off = 0;
+  size_t t_ws_bytes = 0, t_embscr_off = 0, t_a_off = 0;
   int t_final_x = -1;                // tensor handle feeding the output Block
   size_t t_final_ss = 0, t_final_mr = 0;
   int t_conv_in_out = -1;
@@ -122,6 +128,7 @@ struct Builder;
 Regions infer_regions(const sr3_plan* P);
 int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
                 const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
-                const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid);
+                const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid,
+                const DropCfg* drop = nullptr);
 int build_train(sr3_plan* P, int B, int cond_channels);
 }  // namespace sr3

@@ -64,7 +64,21 @@ struct ConvParams {
   int x2_C0, x2_C1;
   const float* x2_w;    // [Cout][x2_C0 + x2_C1]
   const float* x2_bias; // [Cout] or null
+  // Train-mode dropout between the activation and the conv (nn.Dropout of Block, unet.py:86): an
+  // activated input element with NHWC linear index i is kept iff hash32(i * 0x9E3779B9 + drop_seed) >=
+  // drop_thresh and scaled by drop_scale = 1 / (1 - p).  drop_thresh == 0 disables it.  Only defined for
+  // single-source, non-upsampled inputs (block2's input is never a concat).
+  unsigned drop_seed, drop_thresh;
+  float drop_scale;
 };
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_mask(unsigned seed, unsigned idx, unsigned thresh, float scale) {
+  return hash32(idx * 0x9E3779B9U + seed) >= thresh ? scale : 0.f;
+}
 
 // tile_cfg: 0 = auto; im2col-staged implicit GEMM: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128;
 // halo-tile 3x3 stride-1 kernel: 5 = 128x128, 6 = 256(M)x64(N).  ksplit: 0 = auto

@@ -9,7 +9,10 @@ namespace sr3 {
 // dgamma/dbeta[C], and dx0/dx1 (+=) receive the input gradient.  mr[B][G][2] = (mean, rstd).
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, float* gs, float* dgamma, float* dbeta, float* dx0,
-            float* dx1, hipStream_t st);
+            float* dx1, hipStream_t st, unsigned drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f);
+// a = dropout(act(x*scale+shift)) over the virtual concat, materialised for the weight-gradient GEMM
+int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, int act, unsigned drop_seed,
+              unsigned drop_thresh, float drop_scale, float* out, hipStream_t st);
 size_t act_bwd_part_bytes(int B, int HW, int C);
 int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st);
 int zero_insert(const float* g, int B, int Ho, int Wo, int C, float* z, hipStream_t st);

@@ -12,17 +12,6 @@ namespace sr3 {
 
 __device__ __forceinline__ float sigmoid_t(float v) { return __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
-// counter-based dropout mask (train mode only; nn.Dropout(p) of Block, unet.py:86): keep iff
-// hash(seed, element index) >= p * 2^32.  Distributionally a Bernoulli(1-p) mask, regenerated
-// (never stored) by the forward loader, the activation backward and the weight-gradient loader.
-__device__ __forceinline__ unsigned hash32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, unsigned thresh, float inv_keep) {
-  return hash32(idx * 0x9E3779B9U + seed) >= thresh ? inv_keep : 0.f;
-}
-
 // ---------------------------------------------------------------------------------------------
 // T1: activation backward + partial sums.  For the virtual concat x = (x0|x1) with u = x*scale+shift,
 // a = silu(u) (act 2) or a = u (act 1):  du = dA * act'(u)  is written in place of dA, and per
@@ -33,6 +22,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
                                                          const float* __restrict__ x1, int C0, int C1, int HW,
                                                          int LQ, int pix_per_block, const float* __restrict__ ss,
                                                          const float* __restrict__ mr, int groups, int act,
+                                                         unsigned drop_seed, unsigned drop_thresh, float drop_scale,
                                                          double* __restrict__ part) {
   __shared__ double red[256 * 8];
   const int tid = threadIdx.x;
@@ -67,6 +57,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float du = g4[e];
+        if (drop_thresh != 0) du *= drop_mask(drop_seed, (unsigned)(pix * C + c + e), drop_thresh, drop_scale);
         if (act == 2) {
           const float u = fmaf(xv[e], sc[e], sh[e]);
           const float sg = sigmoid_t(u);
@@ -315,6 +306,37 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_pad(const float* __restric
   }
 }
 
+// materialise the activated conv input a = dropout(act(x * scale + shift)) over the virtual concat
+// (input of the weight-gradient GEMM, so that it needs no per-tap recomputation)
+__global__ __launch_bounds__(256) void k_apply_act(const float* __restrict__ x0, const float* __restrict__ x1, int C0,
+                                                    int C1, int HW, const float* __restrict__ ss, int act,
+                                                    unsigned drop_seed, unsigned drop_thresh, float drop_scale,
+                                                    float* __restrict__ out, size_t total4) {
+  const int C = C0 + C1;
+  const int nq = C >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i / nq;
+    const int c = (int)(i - pix * nq) * 4;
+    const int b = (int)(pix / HW);
+    const bool second = c >= C0;
+    const float* xs = second ? x1 : x0;
+    const int Cs = second ? C1 : C0, cs = second ? c - C0 : c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cs);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(ss + ((size_t)b * C + c) * 2);
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(ss + ((size_t)b * C + c) * 2 + 4);
+    v.x = fmaf(v.x, s0.x, s0.y); v.y = fmaf(v.y, s0.z, s0.w); v.z = fmaf(v.z, s1.x, s1.y); v.w = fmaf(v.w, s1.z, s1.w);
+    if (act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * sigmoid_t(v[e]);
+    }
+    if (drop_thresh != 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= drop_mask(drop_seed, (unsigned)(pix * C + c + e), drop_thresh, drop_scale);
+    }
+    *reinterpret_cast<f32x4*>(out + pix * C + c) = v;
+  }
+}
+
 // ---- host wrappers --------------------------------------------------------------------------------
 static void stats_geometry(int B, int HW, int C, int* LQ_, int* cblocks_, int* ppb_, int* slices_) {
   const int nq = C >> 2;
@@ -337,13 +359,13 @@ static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)
 
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, float* gs, float* dgamma, float* dbeta, float* dx0,
-            float* dx1, hipStream_t st) {
+            float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int C = C0 + C1;
   if ((C0 & 3) || (C1 & 3)) { set_error("act_bwd: channels %% 4"); return SR3_E_UNSUPPORTED; }
   int LQ, cblocks, ppb, T;
   stats_geometry(B, HW, C, &LQ, &cblocks, &ppb, &T);
   hipLaunchKernelGGL(k_act_bwd_reduce, dim3(T, cblocks, B), dim3(256), 0, st, dA, x0, x1, C0, C1, HW, LQ, ppb, ss, mr,
-                     groups, act, part);
+                     groups, act, drop_seed, drop_thresh, drop_scale, part);
   SR3_LAUNCH_CHECK("k_act_bwd_reduce");
   hipLaunchKernelGGL(k_gn_bwd_group, dim3(B * groups), dim3(64), 0, st, part, C, T, groups, gamma, gs);
   SR3_LAUNCH_CHECK("k_gn_bwd_group");
@@ -359,6 +381,15 @@ size_t act_bwd_part_bytes(int B, int HW, int C) {
   int LQ, cb, ppb, T;
   stats_geometry(B, HW, C, &LQ, &cb, &ppb, &T);
   return (size_t)B * T * C * 2 * sizeof(double);
+}
+
+int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, int act, unsigned drop_seed,
+              unsigned drop_thresh, float drop_scale, float* out, hipStream_t st) {
+  const size_t total4 = (size_t)B * HW * ((C0 + C1) >> 2);
+  hipLaunchKernelGGL(k_apply_act, dim3(ew_blocks(total4)), dim3(256), 0, st, x0, x1, C0, C1, HW, ss, act, drop_seed,
+                     drop_thresh, drop_scale, out, total4);
+  SR3_LAUNCH_CHECK("k_apply_act");
+  return SR3_OK;
 }
 
 int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st) {

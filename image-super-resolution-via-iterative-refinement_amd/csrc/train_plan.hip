@@ -57,7 +57,8 @@ int wgrad_call(const TrainCtx& X, ConvParams c, const float* dy, float* dw) {
 
 int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels, const float* z, const float* q_ca,
               const float* q_cb, const float* level, const int64_t* tstep, const float* freq, const float* params,
-              float* grads, char* ws, float* loss_out, float grad_scale, int B, hipStream_t st) {
+              float* grads, char* ws, float* loss_out, float grad_scale, int B, hipStream_t st, float dropout_p,
+              unsigned seed) {
   const sr3_unet_desc& d = P->d;
   const int S = d.image_size, G = d.norm_groups;
   const int xc = d.in_channel - cond_channels;
@@ -71,8 +72,12 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   Regions R;
   R.ops = &P->tops; R.stats_off = P->t_stats_off; R.ss_off = P->t_gn_off; R.mr_off = P->t_misc_off;
   R.temb_off = P->t_temb_off; R.film_off = P->t_film_off; R.scratch_off = P->t_scratch_off; R.scratch_bytes = P->t_scratch_bytes;
+  DropCfg dc;
+  dc.seed = seed;
+  dc.thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
+  dc.scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
   rc = run_forward(P, R, x_noisy, cond, cond_channels, level, tstep, freq, nullptr, nullptr, params, ws, eps, B, st, nullptr,
-                   nullptr);
+                   nullptr, &dc);
   if (rc) return rc;
   // ---- loss and its gradient (NHWC, channel dim padded to 4) ----
   float* geps = X.at<float>(P->t_geps_off);
@@ -105,8 +110,11 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (rc) return rc;
       ConvParams c;
       memset(&c, 0, sizeof(c));
-      c.src0 = X.act(r.x0); c.C0 = C; c.B = B; c.Hs = S; c.Ws = S; c.stride = 1; c.ksize = 3; c.Ho = S; c.Wo = S;
-      c.Cout = 4; c.act = 2; c.ss = X.at<float>(P->t_gn_off + r.ss_off);
+      float* abuf = X.at<float>(P->t_a_off);
+      rc = apply_act(X.act(r.x0), nullptr, C, 0, B, S * S, X.at<float>(P->t_gn_off + r.ss_off), 2, 0u, 0u, 1.f, abuf, st);
+      if (rc) return rc;
+      c.src0 = abuf; c.C0 = C; c.B = B; c.Hs = S; c.Ws = S; c.stride = 1; c.ksize = 3; c.Ho = S; c.Wo = S;
+      c.Cout = 4;
       rc = wgrad_call(X, c, geps, dwtmp);
       if (rc) return rc;
       SR3_HIP(hipMemcpyAsync(grads + r.w, dwtmp, (size_t)P->out_ch * 9 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -183,10 +191,12 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       }
       rc = dgrad_conv(X, gsrc, Cout, Hi, Wi, r.ksize, params + r.w, Cout, Cin, dA);
       if (rc) return rc;
+      const bool dropped = r.has_drop && dc.thresh != 0;
+      const unsigned lseed = drop_layer_seed(dc.seed, r.drop_key);
       if (r.act) {
         rc = act_bwd(dA, x0p, x1p, C0, C1, B, x0.H * x0.W, X.at<float>(P->t_gn_off + r.ss_off),
                      X.at<float>(P->t_misc_off + r.mr_off), G, r.act, params + r.gamma, part, gs, grads + r.gamma,
-                     grads + r.beta, d0, d1, st);
+                     grads + r.beta, d0, d1, st, lseed, dropped ? dc.thresh : 0u, dc.scale);
       } else {
         rc = grad_route(dA, C0, C1, B, x0.H, x0.W, r.ups, d0, d1, st);
       }
@@ -194,9 +204,18 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       // 5. weight gradient
       ConvParams c;
       memset(&c, 0, sizeof(c));
-      c.src0 = x0p; c.src1 = x1p; c.C0 = C0; c.C1 = C1; c.B = B; c.Hs = x0.H; c.Ws = x0.W; c.ups = r.ups; c.stride = r.stride;
-      c.ksize = r.ksize; c.Ho = Ho; c.Wo = Wo; c.Cout = Cout; c.act = r.act;
-      c.ss = r.act ? X.at<float>(P->t_gn_off + r.ss_off) : nullptr;
+      c.B = B; c.Hs = x0.H; c.Ws = x0.W; c.ups = r.ups; c.stride = r.stride;
+      c.ksize = r.ksize; c.Ho = Ho; c.Wo = Wo; c.Cout = Cout;
+      if (r.act) {
+        // the activated (and dropped) input is materialised once instead of being recomputed per tap
+        float* abuf = X.at<float>(P->t_a_off);
+        rc = apply_act(x0p, x1p, C0, C1, B, x0.H * x0.W, X.at<float>(P->t_gn_off + r.ss_off), r.act, lseed,
+                       dropped ? dc.thresh : 0u, dc.scale, abuf, st);
+        if (rc) return rc;
+        c.src0 = abuf; c.C0 = Cin; c.C1 = 0;
+      } else {
+        c.src0 = x0p; c.src1 = x1p; c.C0 = C0; c.C1 = C1;
+      }
       rc = wgrad_call(X, c, g, grads + r.w);
       if (rc) return rc;
     }
@@ -226,7 +245,8 @@ size_t sr3_train_workspace_bytes(sr3_plan* plan, int batch, int cond_channels) {
 int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw, int cond_channels, const float* z_nchw,
                    const float* q_ca, const float* q_cb, const float* noise_level, const int64_t* timestep,
                    const float* freq, const float* params, float* grads, void* workspace, size_t workspace_bytes,
-                   float* loss_sum_out, float grad_scale, int batch, void* stream) {
+                   float* loss_sum_out, float grad_scale, float dropout_p, unsigned dropout_seed, int batch,
+                   void* stream) {
   if (!plan || !hr_nchw || !z_nchw || !q_ca || !q_cb || !freq || !params || !grads || !workspace || !loss_sum_out) {
     set_error("null argument");
     return SR3_E_BADARG;
@@ -238,8 +258,10 @@ int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw,
   if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)grads & 15)) { set_error("misaligned pointer"); return SR3_E_ALIGN; }
   if (plan->d.variant == SR3_VARIANT_SR3 && !noise_level) { set_error("SR3 variant needs noise_level"); return SR3_E_BADARG; }
   if (plan->d.variant == SR3_VARIANT_DDPM && !timestep) { set_error("DDPM variant needs timestep"); return SR3_E_BADARG; }
+  if (dropout_p < 0.f || dropout_p >= 1.f) { set_error("dropout_p out of range"); return SR3_E_BADARG; }
   return run_train(plan, hr_nchw, cond_nchw, cond_channels, z_nchw, q_ca, q_cb, noise_level, timestep, freq, params, grads,
-                   static_cast<char*>(workspace), loss_sum_out, grad_scale, batch, static_cast<hipStream_t>(stream));
+                   static_cast<char*>(workspace), loss_sum_out, grad_scale, batch, static_cast<hipStream_t>(stream), dropout_p,
+                   dropout_seed);
 }
 
 int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,

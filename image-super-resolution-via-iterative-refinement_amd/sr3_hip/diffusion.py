@@ -292,7 +292,7 @@ class EngineDiffusion(nn.Module):
         t = t_or_gamma.long()
         return self._q_sample_coef(x_start, self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t], noise)
 
-    def p_losses(self, x_in, noise=None, gamma=None, t=None):
+    def p_losses(self, x_in, noise=None, gamma=None, t=None, drop_seed=None):
         """sr3 diffusion.py:221-246 / ddpm :278-294.  Draws (t, gamma, z) exactly as the reference does
         (numpy global RNG for the SR3 level, torch RNG for z / the DDPM timesteps) unless injected, then
         runs forward + backward in one engine call: returns the sum-reduced L1 loss (0-dim device tensor)
@@ -321,7 +321,7 @@ class EngineDiffusion(nn.Module):
             noise = torch.randn_like(x_start)
         cond = x_in['SR'].contiguous() if self.conditional else None
         return un.train_step(x_start, cond, noise.contiguous(), ca.contiguous(), cb.contiguous(), level, tstep,
-                             grad_scale=1.0 / float(b * c * h * w))
+                             grad_scale=1.0 / float(b * c * h * w), drop_seed=drop_seed)
 
     def forward(self, x, *args, **kwargs):
         return self.p_losses(x, *args, **kwargs)

@@ -136,13 +136,11 @@ class EngineUNet(nn.Module):
                               level_table=level_table, step_dev=step_dev, out=out, **kw)
 
     # ---- training step (forward + backward inside the engine) ------------------------------------
-    def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale):
+    def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, drop_seed=None):
         import ctypes as C
-        if self.dropout != 0 and self.training:
-            if not getattr(self, '_warned_dropout', False):
-                import warnings
-                warnings.warn('engine training step runs without dropout (p=%g ignored in this round)' % self.dropout)
-                self._warned_dropout = True
+        p_drop = self.dropout if self.training else 0.0
+        if drop_seed is None:          # a fresh mask every step, drawn from torch's CPU generator
+            drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         dev = hr.device
         B = hr.shape[0]
         plan = self.plan
@@ -161,8 +159,8 @@ class EngineUNet(nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         L.check(plan.lib.sr3_train_step(plan.handle, L.ptr(hr), L.ptr(cond), cc, L.ptr(z), L.ptr(ca), L.ptr(cb),
                                         L.ptr(level), L.ptr(tstep), L.ptr(self.freq), L.ptr(self.arena.data),
-                                        L.ptr(self.grad_arena), L.ptr(wsv), need, L.ptr(loss), C.c_float(grad_scale), B,
-                                        stream))
+                                        L.ptr(self.grad_arena), L.ptr(wsv), need, L.ptr(loss), C.c_float(grad_scale),
+                                        C.c_float(p_drop), C.c_uint(drop_seed & 0xFFFFFFFF), B, stream))
         return loss[0]
 
     def named_gradients(self):

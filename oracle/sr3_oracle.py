@@ -98,14 +98,36 @@ def time_embedding(t, dim, inv_freq=None):
     return torch.cat([s.sin(), s.cos()], dim=-1).view(*t.shape, dim)
 
 
-def block(sd, p, x, groups):
-    """Block: GroupNorm -> Swish -> (Dropout: eval/identity) -> Conv3x3.  unet.py:80-91"""
+def hash32(x):
+    """The engine's counter-based dropout hash (csrc/sr3_common.h), on numpy uint32."""
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d); x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_mask(shape_nchw, p, seed, key):
+    """Mask * 1/(1-p) the engine applies to an activated NCHW tensor (element index = NHWC linear index)."""
+    b, c, h, w = shape_nchw
+    idx = ((np.arange(b)[:, None, None, None] * h + np.arange(h)[None, None, :, None]) * w
+           + np.arange(w)[None, None, None, :]) * c + np.arange(c)[None, :, None, None]
+    with np.errstate(over='ignore'):
+        lseed = np.uint32((seed + (key + 1) * 0x632BE5AB) & 0xFFFFFFFF)
+        hv = hash32(idx.astype(np.uint32) * np.uint32(0x9E3779B9) + lseed)
+    thresh = np.uint32(int(p * 4294967296.0))
+    return torch.from_numpy((hv >= thresh).astype(np.float32) * np.float32(1.0 / (1.0 - p)))
+
+
+def block(sd, p, x, groups, drop=None):
+    """Block: GroupNorm -> Swish -> Dropout (train mode: drop = (p, seed, key)) -> Conv3x3.  unet.py:80-91"""
     h = F.group_norm(x, groups, sd[p + '.block.0.weight'], sd[p + '.block.0.bias'], eps=1e-5)
     h = swish(h)
+    if drop is not None:
+        h = h * dropout_mask(tuple(h.shape), *drop)
     return F.conv2d(h, sd[p + '.block.3.weight'], sd[p + '.block.3.bias'], padding=1)
 
 
-def resnet_block(sd, p, x, temb, groups, variant):
+def resnet_block(sd, p, x, temb, groups, variant, drop=None):
     """ResnetBlock.forward.  sr3 unet.py:94-110 / ddpm unet.py:78-96"""
     h = block(sd, p + '.block1', x, groups)
     if variant == 'sr3':      # FeatureWiseAffine, use_affine_level=False  (unet.py:34-50)
@@ -114,7 +136,7 @@ def resnet_block(sd, p, x, temb, groups, variant):
     else:                     # mlp = Swish -> Linear, added in place      (ddpm unet.py:81-84,93-94)
         e = F.linear(swish(temb), sd[p + '.mlp.1.weight'], sd[p + '.mlp.1.bias'])
         h = h + e[:, :, None, None]
-    h = block(sd, p + '.block2', h, groups)
+    h = block(sd, p + '.block2', h, groups, drop)
     if (p + '.res_conv.weight') in sd:
         res = F.conv2d(x, sd[p + '.res_conv.weight'], sd[p + '.res_conv.bias'])
     else:
@@ -135,12 +157,14 @@ def self_attention(sd, p, x, groups):
     return out + x
 
 
-def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None):
+def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None, dropout=None):
     """UNet.forward.  sr3 unet.py:235-259 / ddpm unet.py:220-243.
 
     sd: reference-format state dict (OIHW conv weights); x: (B,Cin,H,W) fp32;
     time: (B,1) fp32 noise level (sr3) or (B,) int64 timestep (ddpm).
     taps: optional dict that receives every layer output (name -> tensor).
+    dropout: None (eval) or (p, seed): train-mode dropout with the engine's counter-based mask, keyed per
+    block by its FiLM row offset (cumulative Cout of the preceding blocks in downs, mid, ups order).
     """
     variant = desc['variant']
     groups = desc['norm_groups']
@@ -156,6 +180,8 @@ def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None):
         e = F.linear(e, sd[P + 'time_mlp.1.weight'], sd[P + 'time_mlp.1.bias'])
         temb = F.linear(swish(e), sd[P + 'time_mlp.3.weight'], sd[P + 'time_mlp.3.bias'])
 
+    film_row = [0]
+
     def run(layer, x):
         n = P + layer['name']
         if layer['kind'] == 'conv':
@@ -165,7 +191,9 @@ def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None):
         if layer['kind'] == 'up':                                   # unet.py:58-65
             return F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'),
                             sd[n + '.conv.weight'], sd[n + '.conv.bias'], padding=1)
-        x = resnet_block(sd, n + '.res_block', x, temb, groups, variant)
+        drop = None if dropout is None else (dropout[0], dropout[1], film_row[0])
+        film_row[0] += layer['cout']
+        x = resnet_block(sd, n + '.res_block', x, temb, groups, variant, drop)
         if layer['attn']:
             x = self_attention(sd, n + '.attn', x, groups)
         return x
@@ -302,13 +330,13 @@ def q_sample_sr3(x0, gamma, z):
     return gamma * x0 + (1 - gamma ** 2).sqrt() * z
 
 
-def p_losses_sr3(sd, desc, hr, sr, gamma, z, conditional=True):
+def p_losses_sr3(sd, desc, hr, sr, gamma, z, conditional=True, dropout=None):
     """sr3 diffusion.py:221-246 with injected (gamma (B,), z); L1 sum (set_loss :84-90)."""
     b = hr.shape[0]
     g = gamma.view(b, -1)
     x_noisy = q_sample_sr3(hr, g.view(-1, 1, 1, 1), z)
     inp = torch.cat([sr, x_noisy], dim=1) if conditional else x_noisy
-    eps = unet_forward(sd, desc, inp, g)
+    eps = unet_forward(sd, desc, inp, g, dropout=dropout)
     return (z - eps).abs().sum()
 
 

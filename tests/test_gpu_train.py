@@ -78,3 +78,48 @@ def test_optimize_parameters_one_adam_step(name):
         tot += mask.sum().item()
         bad += ((upd - ref_upd).abs() > 2e-6).sum().item()
     assert tot > 1000 and bad <= 1e-4 * tot, (bad, tot)
+
+
+def test_dropout_training_step_matches_oracle_autograd():
+    """Train-mode dropout (p = 0.2): the engine's counter-based mask is restated in the oracle, whose torch
+    autograd then gives reference loss and gradients for the same mask."""
+    from oracle import sr3_oracle as O
+    import model as Model
+    name = 'sr3_tiny'
+    opt = opt_for(name, phase='train', gpu=True)
+    opt['model']['unet']['dropout'] = 0.2
+    m = Model.create_model(opt)
+    g, sd = load_golden(name)
+    m.netG.load_state_dict(sd, strict=True)
+    m.netG.train()
+    d = G.dev()
+    hr, sr = torch.from_numpy(g['loop/hr']), torch.from_numpy(g['loop/sr'])
+    z, gamma = torch.from_numpy(g['train/z']), torch.from_numpy(g['train/gamma'])
+    seed = 987654321
+    loss = m.netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), gamma=gamma, drop_seed=seed)
+    torch.cuda.synchronize()
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
+    ref_loss = O.p_losses_sr3(sdr, DESCS[name], hr, sr, gamma, z, conditional=True, dropout=(0.2, seed))
+    (ref_loss / hr.numel()).backward()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-5 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    nodrop = float(g['train/loss_sum'])
+    assert abs(float(loss) - nodrop) > 1e-3 * nodrop          # the mask really changed the forward
+    bad = []
+    for key, grad in m.netG.denoise_fn.named_gradients():
+        ref = sdr['denoise_fn.' + key].grad
+        num = (grad.cpu() - ref).norm().item()
+        den = max(ref.norm().item(), 1e-7)
+        if num / den > 1e-4 and den > 1e-6:
+            bad.append((num / den, key))
+    assert not bad, sorted(bad, reverse=True)[:8]
+    # eval mode ignores dropout: sampling path unchanged
+    m.netG.eval()
+
+
+def test_dropout_mask_statistics():
+    from oracle import sr3_oracle as O
+    mk = O.dropout_mask((4, 32, 16, 16), 0.2, 12345, 7)
+    keep = (mk > 0).float().mean().item()
+    assert abs(keep - 0.8) < 0.01 and abs(mk.max().item() - 1.25) < 1e-6
+    mk2 = O.dropout_mask((4, 32, 16, 16), 0.2, 12346, 7)
+    assert (mk != mk2).float().mean().item() > 0.2

@@ -199,6 +199,39 @@ def config_times(out_path):
         del arena, ws, x, out
 
 
+def train_time(B, out_path, iters=5):
+    """SR3 16->128 training step (forward + backward + Adam) timing at batch B."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import model as Model
+    opt = bench.sr3_16_128_opt()
+    opt['phase'] = 'train'
+    opt['model']['unet']['dropout'] = 0
+    torch.manual_seed(0)
+    m = Model.create_model(opt)
+    d = torch.device('cuda:0')
+    data = {'HR': torch.rand(B, 3, 128, 128) * 2 - 1, 'SR': torch.rand(B, 3, 128, 128) * 2 - 1}
+    m.feed_data(data)
+    for _ in range(2):
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(iters):
+        m.optimize_parameters()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / iters
+    fl = 3 * m.netG.denoise_fn.plan.forward_flops(B)
+    rec = dict(what='train_step', B=B, ms=dt * 1e3, img_per_s=B / dt, tflops_3x_fwd=fl / dt / 1e12, l_pix=m.get_current_log()['l_pix'],
+               ws_gb=m.netG.denoise_fn._train_ws.numel() / 1e9)
+    with open(out_path, 'a') as f:
+        f.write(json.dumps(rec) + '\n')
+    print(rec, flush=True)
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=16)
@@ -211,7 +244,11 @@ if __name__ == '__main__':
     ap.add_argument('--tag', default='')
     ap.add_argument('--split', default='')
     ap.add_argument('--configs', action='store_true')
+    ap.add_argument('--train', default='')
     a = ap.parse_args()
+    if a.train:
+        for bb in [int(v) for v in a.train.split(',')]:
+            train_time(bb, os.path.join(OUT, 'probe_train.jsonl'))
     if a.configs:
         config_times(os.path.join(OUT, 'probe_configs.jsonl'))
     if a.split:
