@@ -156,6 +156,47 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
                 all_halo_kernels_tflops=all_tf, by_op_kind=detail)
 
 
+def train_leg(dist, world, rank, dev, batch, steps, warmup):
+    """BASELINE.json configs[2]: SR3 16->128 training step (p_losses + backward + Adam, dropout 0.2 as
+    configured), `batch` images per GPU, data parallel with bucketed RCCL all-reduce of the gradients."""
+    import numpy as np
+    import model as Model
+    opt = sr3_16_128_opt()
+    opt['phase'] = 'train'
+    torch.manual_seed(0)
+    np.random.seed(1234 + rank)
+    m = Model.create_model(opt)
+    g = torch.Generator().manual_seed(77 + rank)
+    data = {'HR': torch.rand(batch, 3, 128, 128, generator=g) * 2 - 1, 'SR': torch.rand(batch, 3, 128, 128, generator=g) * 2 - 1}
+    m.feed_data(data)
+    for _ in range(warmup):
+        m.optimize_parameters()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.optimize_parameters()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / steps * 1e3
+    fl = 3.0 * m.netG.denoise_fn.plan.forward_flops(batch)
+    return {'metric': 'SR3 16->128 training images/sec (p_losses + backward + Adam)', 'value': world * batch / (ms * 1e-3),
+            'unit': 'images/s', 'steps_per_s': 1e3 / ms, 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
+            'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': 0.2, 'optimizer': 'Adam lr 1e-4',
+            'parallelism': 'dp%d, tail-first 32 MB gradient buckets all-reduced (RCCL) as the backward produces them' % world,
+            'tflops_at_3x_forward': fl / (ms * 1e-3) / 1e12,
+            'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -164,6 +205,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE config: 16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--train-steps', type=int, default=10, help='0 disables the training leg')
+    ap.add_argument('--train-batch', type=int, default=64, help='images per GPU (BASELINE config: 64)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -230,6 +273,13 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     images_per_s = world * B / (T * ms_per_step * 1e-3)
 
+    train = None
+    if a.train_steps > 0:
+        # free the sampling state first (graph, workspace) -- the training workspace is ~18 GB at batch 64
+        st['graph'] = None
+        netG._loop_cache = {}
+        torch.cuda.empty_cache()
+        train = train_leg(dist, world, rank, dev, a.train_batch, a.train_steps, 2)
     if rank == 0:
         flops_step = netG.denoise_fn.plan.forward_flops(B)
         rec = {
@@ -248,6 +298,8 @@ def main():
         if not a.no_roofline:
             level = torch.full((B,), 0.5, device=dev)
             rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+        if train is not None:
+            rec['train'] = train
         if not a.no_cpu_baseline and world == 1:
             rec['cpu_baseline'] = cpu_baseline(B)
         print(json.dumps(rec), flush=True)

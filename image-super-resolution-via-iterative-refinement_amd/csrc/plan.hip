@@ -752,6 +752,39 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
   P->t_inpad_off = off; off += al((size_t)B * S * S * 8 * sizeof(float));
   P->t_dwtmp_off = off; off += al(4096 * sizeof(double)) + al(max_dwtmp);      // [loss partials | dw temp]
   P->t_embscr_off = off; off += al((size_t)B * 13 * inner * sizeof(float));
+  // gradient-ready marks: t_unproc_max[k] = largest arena offset (exclusive end) among the parameters whose
+  // gradients are still unwritten once records k .. end have been processed (records < k + the FiLM /
+  // embedding block at the arena head, which is written last)
+  {
+    const size_t nrec = P->recs.size();
+    P->t_unproc_max.assign(nrec + 1, 0);
+    size_t head_end = P->emb_b2 + (size_t)inner;
+    head_end = std::max(head_end, P->film_b + (size_t)P->F);
+    size_t run = head_end;
+    auto pend = [&](size_t off, size_t n) { return off + n; };
+    for (size_t k = 0; k < nrec; ++k) {
+      P->t_unproc_max[k] = run;
+      const Rec& r = P->recs[k];
+      size_t e = 0;
+      if (r.kind == R_ATTN) { /* no parameters */ }
+      else {
+        const int cout = r.kind == R_CONV_OUT ? P->out_ch : P->ttens[r.out >= 0 ? r.out : 0].C;
+        size_t cin = 0;
+        if (r.kind == R_CONV_IN) cin = d.in_channel;
+        else cin = (size_t)P->ttens[r.x0].C + (r.x1 >= 0 ? P->ttens[r.x1].C : 0);
+        e = std::max(e, pend(r.w, (size_t)cout * r.ksize * r.ksize * cin));
+        e = std::max(e, pend(r.bias, (size_t)cout));
+        if (r.act) { e = std::max(e, pend(r.gamma, cin)); e = std::max(e, pend(r.beta, cin)); }
+        if (r.has_q) {
+          const size_t cq = (size_t)P->ttens[r.q0].C + (r.q1 >= 0 ? P->ttens[r.q1].C : 0);
+          e = std::max(e, pend(r.qw, (size_t)cout * cq));
+          e = std::max(e, pend(r.qb, (size_t)cout));
+        }
+      }
+      run = std::max(run, e);
+    }
+    P->t_unproc_max[nrec] = run;
+  }
   P->t_ws_bytes = off;
   P->train_batch = B;
   P->train_cond = cond_channels;

@@ -58,7 +58,7 @@ int wgrad_call(const TrainCtx& X, ConvParams c, const float* dy, float* dw) {
 int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels, const float* z, const float* q_ca,
               const float* q_cb, const float* level, const int64_t* tstep, const float* freq, const float* params,
               float* grads, char* ws, float* loss_out, float grad_scale, int B, hipStream_t st, float dropout_p,
-              unsigned seed) {
+              unsigned seed, int n_marks, const size_t* marks, void* const* mark_events) {
   const sr3_unet_desc& d = P->d;
   const int S = d.image_size, G = d.norm_groups;
   const int xc = d.in_channel - cond_channels;
@@ -94,7 +94,13 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   float* gs = X.at<float>(P->t_gs_off);
   float* dwtmp = reinterpret_cast<float*>(ws + P->t_dwtmp_off + 4096 * sizeof(double));
 
+  int next_mark = 0;
   for (int ri = (int)P->recs.size() - 1; ri >= 0; --ri) {
+    // gradient-ready marks: every parameter at arena offset >= marks[k] has its gradient enqueued
+    while (next_mark < n_marks && P->t_unproc_max[ri + 1] <= marks[next_mark]) {
+      SR3_HIP(hipEventRecord(static_cast<hipEvent_t>(mark_events[next_mark]), st));
+      ++next_mark;
+    }
     const Rec& r = P->recs[ri];
     if (r.kind == R_CONV_OUT) {
       const Tensor& x0 = P->ttens[r.x0];
@@ -220,6 +226,10 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (rc) return rc;
     }
   }
+  while (next_mark < n_marks && P->t_unproc_max[0] <= marks[next_mark]) {
+    SR3_HIP(hipEventRecord(static_cast<hipEvent_t>(mark_events[next_mark]), st));
+    ++next_mark;
+  }
   // ---- embedding MLP and FiLM projections ----
   EmbedBwdParams e;
   memset(&e, 0, sizeof(e));
@@ -229,7 +239,13 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   e.dw1 = grads + P->emb_w1; e.db1 = grads + P->emb_b1; e.dw2 = grads + P->emb_w2; e.db2 = grads + P->emb_b2;
   e.dwf = grads + P->film_w; e.dbf = grads + P->film_b;
   e.scratch = X.at<float>(P->t_embscr_off);
-  return embed_backward(e, st);
+  rc = embed_backward(e, st);
+  if (rc) return rc;
+  while (next_mark < n_marks) {       // whatever is left becomes ready with the head block
+    SR3_HIP(hipEventRecord(static_cast<hipEvent_t>(mark_events[next_mark]), st));
+    ++next_mark;
+  }
+  return SR3_OK;
 }
 
 }  // namespace sr3
@@ -245,8 +261,8 @@ size_t sr3_train_workspace_bytes(sr3_plan* plan, int batch, int cond_channels) {
 int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw, int cond_channels, const float* z_nchw,
                    const float* q_ca, const float* q_cb, const float* noise_level, const int64_t* timestep,
                    const float* freq, const float* params, float* grads, void* workspace, size_t workspace_bytes,
-                   float* loss_sum_out, float grad_scale, float dropout_p, unsigned dropout_seed, int batch,
-                   void* stream) {
+                   float* loss_sum_out, float grad_scale, float dropout_p, unsigned dropout_seed, int n_marks,
+                   const size_t* mark_offsets, void* const* mark_events, int batch, void* stream) {
   if (!plan || !hr_nchw || !z_nchw || !q_ca || !q_cb || !freq || !params || !grads || !workspace || !loss_sum_out) {
     set_error("null argument");
     return SR3_E_BADARG;
@@ -261,7 +277,7 @@ int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw,
   if (dropout_p < 0.f || dropout_p >= 1.f) { set_error("dropout_p out of range"); return SR3_E_BADARG; }
   return run_train(plan, hr_nchw, cond_nchw, cond_channels, z_nchw, q_ca, q_cb, noise_level, timestep, freq, params, grads,
                    static_cast<char*>(workspace), loss_sum_out, grad_scale, batch, static_cast<hipStream_t>(stream), dropout_p,
-                   dropout_seed);
+                   dropout_seed, (mark_offsets && mark_events) ? n_marks : 0, mark_offsets, mark_events);
 }
 
 int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,

@@ -52,7 +52,7 @@ SIGNATURES = {
     'sr3_q_sample': (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     'sr3_train_workspace_bytes': (_Z, [_P, _I, _I]),
     'sr3_train_step': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, C.c_float, C.c_float, C.c_uint,
-                            _I, _P]),
+                            _I, _P, _P, _I, _P]),
     'sr3_adam_step': (_I, [_P, _P, _P, _P, _Z, C.c_float, C.c_float, C.c_float, C.c_float, _I, _P]),
     'sr3_conv_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P,
                           _I, _I, _P, _Z, _P]),

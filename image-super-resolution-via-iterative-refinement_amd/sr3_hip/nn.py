@@ -157,10 +157,25 @@ class EngineUNet(nn.Module):
             self.grad_arena = torch.zeros_like(self.arena.data)
         loss = torch.zeros(1, device=dev)
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        # data parallel (one process per GPU): gradients are summed over ranks, so the 1/(b c h w) factor
+        # uses the GLOBAL batch (model/model.py:52-53 under DataParallel); buckets reduce as they get ready
+        import torch.distributed as tdist
+        dp = tdist.is_available() and tdist.is_initialized() and \
+            (tdist.get_world_size() > 1 or getattr(self, 'force_dp', False))
+        n_marks, offs, evs = 0, None, None
+        if dp:
+            from .dist import GradReducer
+            red = getattr(self, '_reducer', None)
+            if red is None or red.device != dev:
+                red = self._reducer = GradReducer(self.arena.numel(), dev, tdist)
+            grad_scale = grad_scale / tdist.get_world_size()
+            n_marks, offs, evs = red.mark_args()
         L.check(plan.lib.sr3_train_step(plan.handle, L.ptr(hr), L.ptr(cond), cc, L.ptr(z), L.ptr(ca), L.ptr(cb),
                                         L.ptr(level), L.ptr(tstep), L.ptr(self.freq), L.ptr(self.arena.data),
                                         L.ptr(self.grad_arena), L.ptr(wsv), need, L.ptr(loss), C.c_float(grad_scale),
-                                        C.c_float(p_drop), C.c_uint(drop_seed & 0xFFFFFFFF), B, stream))
+                                        C.c_float(p_drop), C.c_uint(drop_seed & 0xFFFFFFFF), n_marks, offs, evs, B, stream))
+        if dp:
+            red.reduce(self.grad_arena, extra=[loss])
         return loss[0]
 
     def named_gradients(self):

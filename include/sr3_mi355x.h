@@ -151,12 +151,17 @@ size_t sr3_train_workspace_bytes(sr3_plan* plan, int batch, int cond_channels);
  * arena and is overwritten.  dropout_p > 0 applies nn.Dropout(p) between Swish and the conv of every
  * block2 (unet.py:83-88,100-101) with a counter-based mask: activated element i (NHWC linear index) of
  * the block with FiLM row offset k is kept iff hash32(i*0x9E3779B9 + dropout_seed + (k+1)*0x632BE5AB) >=
- * p*2^32 and scaled by 1/(1-p); the mask is regenerated, never stored, by the backward. */
+ * p*2^32 and scaled by 1/(1-p); the mask is regenerated, never stored, by the backward.
+ * Gradient-ready marks (data-parallel overlap): mark_offsets[k] (descending arena offsets) / mark_events[k]
+ * (hipEvent_t): event k is recorded on `stream` as soon as the gradient of every parameter at arena offset
+ * >= mark_offsets[k] has been enqueued, so a communication stream can all-reduce that tail bucket while the
+ * rest of the backward still runs (replaces nn.DataParallel's reduce_add, model/networks.py:113-115). */
 int sr3_train_step(sr3_plan* plan, const float* hr_nchw, const float* cond_nchw, int cond_channels,
                    const float* z_nchw, const float* q_ca, const float* q_cb, const float* noise_level,
                    const int64_t* timestep, const float* freq, const float* params, float* grads,
                    void* workspace, size_t workspace_bytes, float* loss_sum_out, float grad_scale, float dropout_p,
-                   unsigned dropout_seed, int batch, void* stream);
+                   unsigned dropout_seed, int n_marks, const size_t* mark_offsets, void* const* mark_events,
+                   int batch, void* stream);
 
 /* torch.optim.Adam step (model/model.py:39-40,55; defaults beta 0.9/0.999, eps 1e-8, no weight decay)
  * fused over the whole arena; `step` is the 1-based step count for the bias corrections. */

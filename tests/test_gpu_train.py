@@ -123,3 +123,33 @@ def test_dropout_mask_statistics():
     assert abs(keep - 0.8) < 0.01 and abs(mk.max().item() - 1.25) < 1e-6
     mk2 = O.dropout_mask((4, 32, 16, 16), 0.2, 12346, 7)
     assert (mk != mk2).float().mean().item() > 0.2
+
+
+def test_data_parallel_path_world1_equals_plain_step():
+    """The DP machinery (gradient-ready events, side-stream bucket all-reduce over RCCL) with one rank must
+    reproduce the plain step bit for bit."""
+    import os
+    import torch.distributed as dist
+    m, g, sd = build_train('sr3_tiny')
+    d = G.dev()
+    data = {'HR': torch.from_numpy(g['loop/hr']).to(d), 'SR': torch.from_numpy(g['loop/sr']).to(d)}
+    z = torch.from_numpy(g['train/z']).to(d)
+    gamma = torch.from_numpy(g['train/gamma'])
+    un = m.netG.denoise_fn
+    l0 = float(m.netG.p_losses(data, noise=z, gamma=gamma))
+    g0 = un.grad_arena.clone()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        un.force_dp = True
+        from sr3_hip.dist import GradReducer
+        un._reducer = GradReducer(un.arena.numel(), d, dist, bucket_bytes=64 << 10)     # several buckets
+        un.grad_arena.zero_()
+        l1 = float(m.netG.p_losses(data, noise=z, gamma=gamma))
+        torch.cuda.synchronize()
+        assert l1 == l0 and torch.equal(un.grad_arena, g0)
+        assert len(un._reducer.buckets) >= 4
+    finally:
+        un.force_dp = False
+        dist.destroy_process_group()
