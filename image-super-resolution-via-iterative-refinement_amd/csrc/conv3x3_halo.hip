@@ -29,7 +29,7 @@ namespace sr3 {
 __device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
 
-template <int WAVES_M, int WAVES_N, bool X2>
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP>
 __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   constexpr int LDK = 36, BK = 32;
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
           v.z = fmaf(v.z, sb.x, sb.y);
           v.w = fmaf(v.w, sb.z, sb.w);
           if (cur_act == 2) { v.x = silu_h(v.x); v.y = silu_h(v.y); v.z = silu_h(v.z); v.w = silu_h(v.w); }
-          if (p.drop_thresh != 0) {      // segment 1 only (cur_act != 0), single source => linear NHWC index
+          if (DROP) {                    // segment 1 only (cur_act != 0), single source => linear NHWC index
             const unsigned i0 = (unsigned)(hpix[j] * p.C0 + cur_c);
             v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
             v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
 namespace {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-template <int WAVES_M, int WAVES_N, bool X2>
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP>
 int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
@@ -378,7 +378,7 @@ int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int smem_epi = 4 * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr_set = false;
-  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2>;
+  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP>;
   if (!attr_set) {
     SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -415,8 +415,12 @@ bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
 int halo_stats_slices(const HaloGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 1; }
 
 int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
-  if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true>(p, g, st) : launch_halo<2, 2, true>(p, g, st);
-  return cfg == 6 ? launch_halo<4, 1, false>(p, g, st) : launch_halo<2, 2, false>(p, g, st);
+  if (p.drop_thresh != 0) {       // train-mode block2 convs only
+    if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true, true>(p, g, st) : launch_halo<2, 2, true, true>(p, g, st);
+    return cfg == 6 ? launch_halo<4, 1, false, true>(p, g, st) : launch_halo<2, 2, false, true>(p, g, st);
+  }
+  if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true, false>(p, g, st) : launch_halo<2, 2, true, false>(p, g, st);
+  return cfg == 6 ? launch_halo<4, 1, false, false>(p, g, st) : launch_halo<2, 2, false, false>(p, g, st);
 }
 
 }  // namespace sr3

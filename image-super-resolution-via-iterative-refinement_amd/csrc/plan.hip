@@ -5,6 +5,7 @@
 // Nothing here is a translation of the reference modules: the forward is compiled once per batch
 // size into a flat list of kernel launches over a liveness-planned NHWC workspace.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -372,6 +373,13 @@ struct Builder {
     o.ss_rel = act_mode ? cur_ss : 0;
     o.has_drop = train && drop_key >= 0; o.drop_key = (unsigned)(drop_key >= 0 ? drop_key : 0);
     conv_pick(c, o.tile_cfg, o.ksplit);
+    // the 256x64 dropout instantiation spills registers but still beats the half-empty 128x128 tile on the
+    // 64-channel layers (A/B on MI355X: 219.7 vs 222.2 ms per step); SR3_DROP_CFG5 forces the latter
+    static const bool use5 = getenv("SR3_DROP_CFG5") != nullptr;
+    if (o.has_drop && o.tile_cfg == 6 && use5) {
+      o.tile_cfg = 5; o.ksplit = P->ksplit;
+      conv_pick(c, o.tile_cfg, o.ksplit);
+    }
     if (train) {
       Rec r;
       r.kind = R_CONV; r.x0 = x0; r.x1 = x1; r.out = out; r.r0 = r0; r.r1 = r1; r.q0 = q0; r.q1 = q1;

@@ -16,7 +16,8 @@ __device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_r
 
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const float* __restrict__ dy,
-                                                        float* __restrict__ slabs, int chunks_per_split) {
+                                                        float* __restrict__ slabs, int chunks_per_split, int logW,
+                                                        int logHW) {
   constexpr int LDN = TN + 4, LDC = TC + 4;
   constexpr int YR = TN / 32, AR = TC / 32;      // float4 loads per thread per chunk (TN/4 * 32 / 256)
   constexpr int WN = TN / 2, WC = TC / 2;
@@ -60,9 +61,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const
       const int m = chunk * 32 + lpx + 8 * i;
       const bool mv = m < M;
       const int me = mv ? m : 0;
-      const int b = me / HoWo;
-      const int rem = me - b * HoWo;
-      const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+      int b, oh, ow;
+      if (logW >= 0) {            // power-of-two feature maps (every real config): shifts instead of divisions
+        b = me >> logHW;
+        const int rem = me & (HoWo - 1);
+        oh = rem >> logW; ow = rem & (p.Wo - 1);
+      } else {
+        b = me / HoWo;
+        const int rem = me - b * HoWo;
+        oh = rem / p.Wo; ow = rem - oh * p.Wo;
+      }
       yok[i] = mv && nv;
       ry[i] = *reinterpret_cast<const f32x4*>(dy + (yok[i] ? me * p.Cout + n : 0));
       const int ih = oh * p.stride + fr - pad, iw = ow * p.stride + fs - pad;
@@ -195,7 +203,10 @@ int launch_wgrad(const WgradParams& p, int msplit, int cps, hipStream_t st) {
   const int Cin = p.c.C0 + p.c.C1;
   const int taps = p.c.ksize * p.c.ksize;
   dim3 grid(cdivw(p.c.Cout, TN) * cdivw(Cin, TC), taps, msplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p.c, p.dy, msplit > 1 ? p.slabs : p.dw, cps);
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  int logW = lg(p.c.Wo), logHW = lg(p.c.Ho * p.c.Wo);
+  if (logW < 0 || logHW < 0) logW = logHW = -1;
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p.c, p.dy, msplit > 1 ? p.slabs : p.dw, cps, logW, logHW);
   SR3_LAUNCH_CHECK("k_conv_wgrad");
   return SR3_OK;
 }
