@@ -699,6 +699,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       const Tensor& o = P->ttens[r.out];
       c.C0 = x0.C; c.C1 = r.x1 >= 0 ? P->ttens[r.x1].C : 0; c.B = B; c.Hs = x0.H; c.Ws = x0.W; c.ups = r.ups;
       c.stride = r.stride; c.ksize = r.ksize; c.Ho = o.H; c.Wo = o.W; c.Cout = o.C;
+      if (r.act) { c.C0 = c.C0 + c.C1; c.C1 = 0; }     // run time: the activated input is materialised (single source)
       max_slab = std::max(max_slab, wgrad_slab_bytes(c, nullptr));
       max_part = std::max(max_part, act_bwd_part_bytes(B, x0.H * x0.W, c.C0 + c.C1));
       max_part = std::max(max_part, (size_t)B * chan_stats_slices(B, o.H * o.W, o.C) * o.C * 2 * sizeof(double));

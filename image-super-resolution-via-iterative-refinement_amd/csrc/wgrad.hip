@@ -162,6 +162,130 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 9-tap variant for the 3x3 stride-1 convs (the bulk of the weight-gradient FLOPs).  A workgroup owns a
+// 64 x 64 (n, c) tile of ALL nine taps: per 32-pixel chunk (a row segment, or 2-4 whole rows of a narrow
+// map) it stages dOut[32][64] and the (rows+2) x (cols+2) halo of the materialised activated input ONCE and
+// every tap reads its B fragments from the halo at a shifted pixel -- 144 MFMAs per wave per barrier and
+// 3.5x fewer staged bytes per MFMA than one tap at a time.  a: [B,H,W,Cin] single source (k_apply_act).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad9(const float* __restrict__ a, int Cin,
+                                                         const float* __restrict__ dy, int Cout, int B, int H, int W,
+                                                         int logW, float* __restrict__ slabs, int chunks_per_split) {
+  constexpr int T = 64, LD = 68;
+  constexpr int HPX_MAX = 102;                       // 3 x 34 halo pixels (W >= 32); 4 x 18, 6 x 10 for W = 16, 8
+  constexpr int HI = (HPX_MAX * 16 + 255) / 256;     // halo float4 items per thread (7)
+  constexpr int STAGE = (32 + HPX_MAX) * LD;
+  extern __shared__ f32x4 smem_v[];
+  float* smem = reinterpret_cast<float*>(smem_v);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wc = W < 32 ? W : 32;                    // chunk = RPC rows x Wc columns = 32 pixels
+  const int logWc = logW < 5 ? logW : 5;
+  const int RPC = 32 >> logWc;
+  const int HWp = Wc + 2, HR = RPC + 2, HPX = HR * HWp;
+  const int cpr = W >> logWc;                        // chunks per image row (W >= 32) else 1
+  const int chunks_per_img = (H * W) >> 5;
+  const int nchunks = B * chunks_per_img;
+  const int tiles_c = (Cin + T - 1) / T;
+  const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_n * tiles_c;
+  const int ch0 = blockIdx.z * chunks_per_split;
+  const int ch1 = min(nchunks, ch0 + chunks_per_split);
+
+  // loader items (fixed per thread): halo pixel (tid>>4) + 16 j, channel quad tid & 15
+  const int lq = tid & 15, lp = tid >> 4;
+  int hy[HI], hx[HI];
+#pragma unroll
+  for (int j = 0; j < HI; ++j) {
+    const int hp = lp + 16 * j;
+    hy[j] = hp < HPX ? hp / HWp : -1000;
+    hx[j] = hp < HPX ? hp - (hp / HWp) * HWp : 0;
+  }
+  f32x4 rh[HI], ry[2];
+  bool hok[HI], yok[2];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](int chunk) {
+    const int b = chunk / chunks_per_img;
+    const int ci = chunk - b * chunks_per_img;
+    const int oh0 = (W >= 32) ? ci / cpr : ci * RPC;
+    const int ow0 = (W >= 32) ? (ci - (ci / cpr) * cpr) * 32 : 0;
+    const int c = tile_c * T + lq * 4;
+    const int n = tile_n * T + lq * 4;
+    const bool cv = c < Cin, nv = n < Cout;
+#pragma unroll
+    for (int j = 0; j < HI; ++j) {
+      const int ih = oh0 + hy[j] - 1, iw = ow0 + hx[j] - 1;
+      const bool ok = cv && hy[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      hok[j] = ok;
+      rh[j] = *reinterpret_cast<const f32x4*>(a + (ok ? ((b * H + ih) * W + iw) * Cin + c : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int px = lp + 16 * i;                    // 0..31
+      const int oh = oh0 + (px >> logWc), ow = ow0 + (px & (Wc - 1));
+      yok[i] = nv;
+      ry[i] = *reinterpret_cast<const f32x4*>(dy + (nv ? ((b * H + oh) * W + ow) * Cout + n : 0));
+    }
+  };
+  auto store = [&](int st) {
+    float* Ys = smem + st * STAGE;
+    float* Hs = Ys + 32 * LD;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Ys[(lp + 16 * i) * LD + lq * 4]) = yok[i] ? ry[i] : zero;
+#pragma unroll
+    for (int j = 0; j < HI; ++j) {
+      const int hp = lp + 16 * j;
+      if (hp < HPX) *reinterpret_cast<f32x4*>(&Hs[hp * LD + lq * 4]) = hok[j] ? rh[j] : zero;
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const int wave_n = wave >> 1, wave_c = wave & 1;
+  const int ncol = wave_n * 32 + (lane & 31);
+  const int ccol = wave_c * 32 + (lane & 31);
+  const int khalf = lane >> 5;
+
+  if (ch0 < ch1) {
+    load(ch0);
+    store(0);
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+      const int cur = (ch - ch0) & 1;
+      const bool more = ch + 1 < ch1;
+      if (more) load(ch + 1);
+      const float* Ys = smem + cur * STAGE;
+      const float* Hs = Ys + 32 * LD;
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int px = 2 * kk + khalf;
+        const float av = Ys[px * LD + ncol];
+        const int hbase = (px >> logWc) * HWp + (px & (Wc - 1));      // halo pixel of tap (0,0)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float bv = Hs[(hbase + (t / 3) * HWp + (t % 3)) * LD + ccol];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+      if (more) store(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  float* dst = slabs + (size_t)blockIdx.z * Cout * 9 * Cin;
+  const int c = tile_c * T + wave_c * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = tile_n * T + wave_n * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < Cout && c < Cin) dst[((size_t)n * 9 + t) * Cin + c] = acc[t][r];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int msplit, size_t n4,
                                                        float* __restrict__ dw) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -173,9 +297,32 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 
 namespace {
 inline int cdivw(int a, int b) { return (a + b - 1) / b; }
+inline int ilog2w(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+// the 9-tap kernel covers 3x3 stride-1 non-upsampled single-source convs on power-of-two maps with W >= 8
+bool wgrad9_ok(const ConvParams& c) {
+  if (c.ksize != 3 || c.stride != 1 || c.ups != 0 || c.C1 != 0 || c.act != 0) return false;
+  const int lw = ilog2w(c.Wo);
+  if (lw < 3 || c.Ho != c.Hs || c.Wo != c.Ws) return false;
+  const int Wc = c.Wo < 32 ? c.Wo : 32;
+  const int rpc = 32 / Wc;
+  return c.Ho % rpc == 0 && (c.Ho * c.Wo) % 32 == 0;
+}
 void wgrad_geometry(const ConvParams& c, int* tn, int* tc, int* msplit, int* cps) {
   const int Cin = c.C0 + c.C1;
   const int taps = c.ksize * c.ksize;
+  if (wgrad9_ok(c)) {
+    *tn = 64; *tc = 64;
+    const long tiles = (long)cdivw(c.Cout, 64) * cdivw(Cin, 64);
+    const int nchunks = c.B * c.Ho * c.Wo / 32;
+    long ms = (512 + tiles - 1) / tiles;
+    const long cap = nchunks / 2 > 1 ? nchunks / 2 : 1;
+    if (ms > cap) ms = cap;
+    if (ms < 1) ms = 1;
+    int per = cdivw(nchunks, (int)ms);
+    *msplit = cdivw(nchunks, per);
+    *cps = per;
+    return;
+  }
   const bool small = c.Cout <= 64 || Cin <= 64;
   *tn = small ? 64 : 128;
   *tc = small ? 64 : 128;
@@ -233,7 +380,22 @@ int conv_wgrad(const WgradParams& p, hipStream_t st) {
   wgrad_geometry(c, &tn, &tc, &ms, &cps);
   if (ms != p.msplit) { set_error("wgrad: msplit mismatch (%d vs %d)", ms, p.msplit); return SR3_E_BADARG; }
   if (ms > 1 && !p.slabs) { set_error("wgrad: slabs required"); return SR3_E_BADARG; }
-  int rc = tn == 128 ? launch_wgrad<128, 128>(p, ms, cps, st) : launch_wgrad<64, 64>(p, ms, cps, st);
+  int rc;
+  if (wgrad9_ok(c)) {
+    constexpr int smem9 = 2 * (32 + 102) * 68 * 4;
+    static bool attr9 = false;
+    if (!attr9) {
+      SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad9), hipFuncAttributeMaxDynamicSharedMemorySize, smem9));
+      attr9 = true;
+    }
+    dim3 grid(cdivw(c.Cout, 64) * cdivw(Cin, 64), 1, ms);
+    hipLaunchKernelGGL(k_conv_wgrad9, grid, dim3(256), smem9, st, c.src0, Cin, p.dy, c.Cout, c.B, c.Ho, c.Wo, ilog2w(c.Wo),
+                       ms > 1 ? p.slabs : p.dw, cps);
+    SR3_LAUNCH_CHECK("k_conv_wgrad9");
+    rc = SR3_OK;
+  } else {
+    rc = tn == 128 ? launch_wgrad<128, 128>(p, ms, cps, st) : launch_wgrad<64, 64>(p, ms, cps, st);
+  }
   if (rc) return rc;
   if (ms > 1) {
     const size_t n4 = (size_t)c.Cout * c.ksize * c.ksize * Cin / 4;
