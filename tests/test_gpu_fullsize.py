@@ -73,3 +73,37 @@ def test_fullsize_forward_and_step_vs_oracle(name):
                                  condition_x=None if cond is None else cond.to(d), noise=z.to(d))
     G.assert_close(got_step.cpu(), ref_step, what=name + ' p_sample')
     print('%s: eps max abs err %.2e (|ref|max %.2f)' % (name, err, ref.abs().max().item()))
+
+
+def test_config1_ten_step_loop_all_frames():
+    """BASELINE.json configs[0]: config/sr_sr3_16_128.json, batch 1, 10 reverse steps (the `-debug` size):
+    feed_data -> test(continous=True) through the drop-in DDPM wrapper, all 11 returned frames vs the oracle
+    loop on the same x_T / z sequence."""
+    from oracle import sr3_oracle as O
+    import model as Model
+    c = CONFIGS['sr3_16_128']
+    opt = make_opt(c, T=10)
+    opt['phase'] = 'val'
+    torch.manual_seed(21)
+    m = Model.create_model(opt)
+    sd = {k: v.clone().cpu() for k, v in m.netG.state_dict().items()}
+    m.netG.show_progress = False
+    desc = O.desc_from_opt(opt)
+    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
+    g = torch.Generator().manual_seed(3)
+    sr = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    hr = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    x_T = torch.randn(1, 3, 128, 128, generator=g)
+    zs = torch.randn(10, 1, 3, 128, 128, generator=g)
+    d = G.dev()
+    m.feed_data({'HR': hr, 'SR': sr})
+    out = m.netG.p_sample_loop(m.data['SR'], continous=True, x_T=x_T.to(d), noise_seq=zs.to(d)).cpu()
+    with torch.no_grad():
+        ref = O.p_sample_loop(sd, desc, tab, sr, x_T, zs, conditional=True, continous=True)
+    assert tuple(out.shape) == tuple(ref.shape) == (11, 3, 128, 128)
+    G.assert_close(out, ref, tol=1e-4, what='config 1 loop')
+    # and the seeded production path (graph replay) returns the same shapes through test()
+    m.test(continous=True)
+    assert tuple(m.SR.shape) == (11, 3, 128, 128) and bool(torch.isfinite(m.SR).all())
+    vis = m.get_current_visuals(need_LR=False)
+    assert tuple(vis['SR'].shape) == (11, 3, 128, 128) and tuple(vis['INF'].shape) == (1, 3, 128, 128)
