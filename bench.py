@@ -131,8 +131,8 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             a[0] += ms[i]
             a[1] += fl[i]
             a[2] += 1
-    names = {55: 'k_conv3x3_halo<2,2,false>', 56: 'k_conv3x3_halo<4,1,false>', 57: 'k_conv3x3_halo<2,2,true>',
-             58: 'k_conv3x3_halo<4,1,true>'}
+    names = {55: 'k_conv3x3_halo<2,2,false,false>', 56: 'k_conv3x3_halo<4,1,false,false>',
+             57: 'k_conv3x3_halo<2,2,true,false>', 58: 'k_conv3x3_halo<4,1,true,false>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]

@@ -362,7 +362,10 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       units = nchunks * taps; min_units = 6;
     }
     int ks = 1;
-    if (tiles < 384) {
+    // split K until the grid gives ~2 workgroups per CU (in-run A/B on MI355X: threshold 384 -> 14.87 ms per
+    // step, 256 -> 14.96 ms; SR3_KSPLIT_TILES overrides)
+    static const long split_below = getenv("SR3_KSPLIT_TILES") ? atol(getenv("SR3_KSPLIT_TILES")) : 384;
+    if (tiles < split_below) {
       ks = (int)((512 + tiles - 1) / tiles);
       const int cap = units / min_units > 1 ? units / min_units : 1;
       if (ks > cap) ks = cap;
