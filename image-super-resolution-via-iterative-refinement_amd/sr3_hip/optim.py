@@ -40,18 +40,54 @@ class EngineAdam(object):
                                        arena.numel(), C.c_float(d['lr']), C.c_float(d['betas'][0]),
                                        C.c_float(d['betas'][1]), C.c_float(d['eps']), self.step_count, stream))
 
+    # ---- checkpoint format: torch.optim.Adam's (model/model.py:137-142, 160-163) --------------------------
+    # One state entry per parameter in `netG.parameters()` order (= the plan table order, which is the
+    # reference's registration order), moments in the reference shapes (OIHW), so `*_opt.pth` files are
+    # interchangeable with the reference in both directions.
     def state_dict(self):
-        return {'state': {0: {'step': self.step_count,
-                              'exp_avg': None if self.exp_avg is None else self.exp_avg.cpu(),
-                              'exp_avg_sq': None if self.exp_avg_sq is None else self.exp_avg_sq.cpu()}},
-                'param_groups': [dict(self.defaults, params=[0])], 'engine_arena': True}
+        un = self.netG.denoise_fn
+        plan = un.plan
+        state = {}
+        if self.exp_avg is not None and self.step_count > 0:
+            for i, e in enumerate(plan.table):
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': plan.view(self.exp_avg, e).detach().cpu().clone().contiguous(),
+                            'exp_avg_sq': plan.view(self.exp_avg_sq, e).detach().cpu().clone().contiguous()}
+        d = self.defaults
+        group = {'lr': d['lr'], 'betas': tuple(d['betas']), 'eps': d['eps'], 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(plan.table)))}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        st = sd.get('state', {}).get(0, {})
-        self.step_count = int(st.get('step', sd.get('engine_step', 0)))
-        if st.get('exp_avg') is not None:
-            self.exp_avg = st['exp_avg'].clone()
-            self.exp_avg_sq = st['exp_avg_sq'].clone()
+        un = self.netG.denoise_fn
+        plan = un.plan
+        groups = sd.get('param_groups') or [{}]
+        for k in ('lr', 'eps'):
+            if k in groups[0]:
+                self.defaults[k] = groups[0][k]
+        if 'betas' in groups[0]:
+            self.defaults['betas'] = tuple(groups[0]['betas'])
+        state = sd.get('state', {})
+        if not state:
+            self.step_count = 0
+            return
+        if len(state) != len(plan.table):
+            raise ValueError('optimizer state has %d entries, the model has %d parameters' % (len(state), len(plan.table)))
+        arena = un.arena.data
+        self.exp_avg = torch.zeros_like(arena)
+        self.exp_avg_sq = torch.zeros_like(arena)
+        steps = set()
+        for i, e in enumerate(plan.table):
+            st = state[i] if i in state else state[str(i)]
+            if tuple(st['exp_avg'].shape) != tuple(e['shape']):
+                raise ValueError('optimizer state %d (%s): shape %s vs %s' % (i, e['name'], tuple(st['exp_avg'].shape), e['shape']))
+            plan.view(self.exp_avg, e).copy_(st['exp_avg'].to(arena.device, torch.float32))
+            plan.view(self.exp_avg_sq, e).copy_(st['exp_avg_sq'].to(arena.device, torch.float32))
+            steps.add(int(float(st['step'])))
+        if len(steps) != 1:
+            raise ValueError('per-parameter Adam step counts differ: %s' % sorted(steps))
+        self.step_count = steps.pop()
 
 
 def make_optimizer(netG, lr):

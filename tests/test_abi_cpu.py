@@ -119,3 +119,32 @@ def test_engine_has_no_cpu_fallback():
     m.feed_data({'HR': torch.zeros(1, 3, 16, 16), 'SR': torch.zeros(1, 3, 16, 16)})
     with pytest.raises(L.Sr3Error):
         m.test()
+
+
+def test_optimizer_state_is_torch_adam_format():
+    """`*_opt.pth` interchange: the engine's optimizer state loads into a real
+    torch.optim.Adam built over reference-shaped parameters, and back."""
+    import model as Model
+    opt = opt_for('sr3_tiny', phase='train', gpu=False)
+    m = Model.create_model(opt)
+    un = m.netG.denoise_fn
+    optG = m.optG
+    g = torch.Generator().manual_seed(5)
+    optG.exp_avg = torch.randn(un.arena.numel(), generator=g)
+    optG.exp_avg_sq = torch.rand(un.arena.numel(), generator=g)
+    optG.step_count = 7
+    sd = optG.state_dict()
+    params = [torch.nn.Parameter(p.detach().clone().contiguous()) for p in un.parameters()]
+    ref = torch.optim.Adam(params, lr=1e-4)
+    ref.load_state_dict(sd)                                  # torch accepts the layout
+    rsd = ref.state_dict()
+    assert len(rsd['state']) == len(un.plan.table) == 162
+    k = [i for i, e in enumerate(un.plan.table) if e['pack'] == 1][3]       # a 3x3 conv weight (OIHW)
+    assert tuple(rsd['state'][k]['exp_avg'].shape) == tuple(un.plan.table[k]['shape'])
+    # and back: a torch state dict loads into the engine optimizer bit for bit
+    optG2 = Model.create_model(opt_for('sr3_tiny', phase='train', gpu=False)).optG
+    optG2.load_state_dict(rsd)
+    assert optG2.step_count == 7
+    for e in un.plan.table:
+        assert torch.equal(un.plan.view(optG2.exp_avg, e), un.plan.view(optG.exp_avg, e)), e['name']
+        assert torch.equal(un.plan.view(optG2.exp_avg_sq, e), un.plan.view(optG.exp_avg_sq, e))
