@@ -279,7 +279,10 @@ def main():
         st['graph'] = None
         netG._loop_cache = {}
         torch.cuda.empty_cache()
-        train = train_leg(dist, world, rank, dev, a.train_batch, a.train_steps, 2)
+        try:
+            train = train_leg(dist, world, rank, dev, a.train_batch, a.train_steps, 2)
+        except Exception as e:                      # the headline line must survive a failing extra leg
+            train = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         flops_step = netG.denoise_fn.plan.forward_flops(B)
         rec = {
@@ -297,11 +300,17 @@ def main():
         }
         if not a.no_roofline:
             level = torch.full((B,), 0.5, device=dev)
-            rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+            try:
+                rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+            except Exception as e:
+                rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if train is not None:
             rec['train'] = train
         if not a.no_cpu_baseline and world == 1:
-            rec['cpu_baseline'] = cpu_baseline(B)
+            try:
+                rec['cpu_baseline'] = cpu_baseline(B)
+            except Exception as e:
+                rec['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
         print(json.dumps(rec), flush=True)
     if dist:
         dist.barrier()

@@ -581,13 +581,12 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
   float* film = reinterpret_cast<float*>(ws + R.film_off);
-  int last_hw = 0;
   for (const Op& o : *R.ops) {
     int rc = SR3_OK;
     if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
     ++op_index;
     switch (o.kind) {
-      case OP_MEMSET:
+      case OP_RESERVED:
         break;
       case OP_EMBED: {
         EmbedParams e;
@@ -620,7 +619,6 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
                          o.has_st1 ? o.i1 : 0, o.has_st1 ? o.i4 : 0, B, o.i2, d.norm_groups, params + o.p0,
                          params + o.p1, 1e-5f, reinterpret_cast<float*>(ws + R.ss_off + o.ss_rel), st,
                          o.has_mr ? reinterpret_cast<float*>(ws + R.mr_off + o.mr_rel) : nullptr);
-        last_hw = o.i2;
         break;
       case OP_CONV: {
         ConvParams c = o.cp;
@@ -659,7 +657,6 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
     if (rc) return rc;
   }
   if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
-  (void)last_hw;
   return SR3_OK;
 }
 
@@ -852,6 +849,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   const int prev = *slot;
   *slot = value;
   plan->built_batch = -1;
+  plan->train_batch = -1;
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }

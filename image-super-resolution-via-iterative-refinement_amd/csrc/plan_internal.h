@@ -40,7 +40,8 @@ struct Layer {
   ResLayer res;
 };
 
-enum OpKind { OP_MEMSET, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_ATTN, OP_CONV_OUT };
+// numeric values are part of sr3_unet_forward_profile's op_kind encoding (kind * 10)
+enum OpKind { OP_RESERVED, OP_EMBED, OP_CONV_IN, OP_STATS, OP_FOLD, OP_CONV, OP_ATTN, OP_CONV_OUT };
 
 struct Op {
   OpKind kind;

@@ -1,8 +1,9 @@
 // Weight gradient of every conv of the UNet (autograd of nn.Conv2d in the reference's
 // `l_pix.backward()`, model/model.py:54) as a GEMM over pixels on v_mfma_f32_32x32x2_f32:
 //     dw[n][tap][c] = sum_{m = (b, oh, ow)} dy[m][n] * a[b, oh*s + r - pad, ow*s + q - pad, c]
-// with a = the conv's activated input (GroupNorm affine + SiLU of the virtual concat x0|x1, nearest
-// x2 upsample folded into the address), recomputed on the fly instead of being stored by the forward.
+// with a = the conv's activated input.  The training driver materialises a = dropout(silu(gn(x0|x1))) once per
+// conv (k_apply_act) and passes it as a single source; the generic kernel can also apply the prologue itself and
+// folds the nearest x2 upsample / stride into the address (used for the Upsample / Downsample / 1x1 convs).
 // Both operands are pixel-major ([m][channels], the natural NHWC order), so a k-step reads its
 // fragments with conflict-free ds_read_b32 (lanes along channels).  Workgroup tile TN x TC of one
 // filter tap; pixels are walked in chunks of 32, register-prefetched and double-buffered; the pixel
@@ -19,7 +20,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const
                                                         float* __restrict__ slabs, int chunks_per_split, int logW,
                                                         int logHW) {
   constexpr int LDN = TN + 4, LDC = TC + 4;
-  constexpr int YR = TN / 32, AR = TC / 32;      // float4 loads per thread per chunk (TN/4 * 32 / 256)
   constexpr int WN = TN / 2, WC = TC / 2;
   constexpr int MI = WN / 32, NI = WC / 32;
   constexpr int STAGE = 32 * (LDN + LDC);
