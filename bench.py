@@ -31,6 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, 'image-super-resolution-via-iterative-refi
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
 
 
 def sr3_16_128_opt(n_timestep=2000):
@@ -131,8 +132,12 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             a[0] += ms[i]
             a[1] += fl[i]
             a[2] += 1
-    names = {55: 'k_conv3x3_halo<2,2,false,false>', 56: 'k_conv3x3_halo<4,1,false,false>',
-             57: 'k_conv3x3_halo<2,2,true,false>', 58: 'k_conv3x3_halo<4,1,true,false>'}
+    # template arguments: <WAVES_M, WAVES_N, fused 1x1 segment, dropout, 0 = fp32 MFMA | 1 = 3 x bf16 split MFMA>
+    names = {55: 'k_conv3x3_halo<2,2,false,false,0>', 56: 'k_conv3x3_halo<4,1,false,false,0>',
+             57: 'k_conv3x3_halo<2,2,true,false,0>', 58: 'k_conv3x3_halo<4,1,true,false,0>',
+             255: 'k_conv3x3_halo<4,2,false,false,0>', 257: 'k_conv3x3_halo<4,2,true,false,0>',
+             155: 'k_conv3x3_halo<2,2,false,false,1>', 157: 'k_conv3x3_halo<2,2,true,false,1>',
+             355: 'k_conv3x3_halo<4,2,false,false,1>', 357: 'k_conv3x3_halo<4,2,true,false,1>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -148,12 +153,55 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             traffic = json.load(f)['sr3::' + names[dom].replace(',', ', ')]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         pass
-    return dict(bound='mfma', kernel=names[dom] + ' (v_mfma_f32_32x32x2_f32)', achieved=achieved,
-                peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s', frac=achieved / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
+    is_split = names[dom].endswith(',1>')
+    # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
+    return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
+                                                   else ' (v_mfma_f32_32x32x2_f32)'), achieved=achieved,
+                peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic,
                 traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/r01_bench_hbm_pmc.csv',
                 avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,
                 flops_per_launch=flops / launches, share_of_forward_time=(t_ms / reps) / total_ms,
                 all_halo_kernels_tflops=all_tf, by_op_kind=detail)
+
+
+def split_bf16_leg(netG, cond, T, dev, steps=200):
+    """Secondary, NOT the headline: the same reverse step with the opt-in `split_bf16` plan option (halo-tile
+    convs with Cout > 64 on v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 terms, six products,
+    fp32 accumulate).  Reports its step time and how far its eps is from the exact-fp32 path's on the same input."""
+    un = netG.denoise_fn
+    B = cond.shape[0]
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn(B, 3, 128, 128, device=dev, generator=g)
+    level = torch.full((B, 1), 0.6, device=dev)
+    eps_exact = un(x, level, cond=cond).clone()
+    un.plan.set_option('split_bf16', 1)
+    try:
+        eps_split = un(x, level, cond=cond).clone()
+        shape = tuple(cond.shape)
+        st = netG._loop_state(shape, shape, dev)
+        st['cond'].copy_(cond)
+        st['img'].copy_(torch.randn(shape, device=dev))
+        st['step'].fill_(T - 1)
+        netG._capture(st)
+        for _ in range(5):
+            st['graph'].replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st['graph'].replay()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        finite = bool(torch.isfinite(st['img']).all().item())
+    finally:
+        un.plan.set_option('split_bf16', 0)
+        netG._loop_cache = {}
+    fl = un.plan.forward_flops(B)
+    return dict(ms_per_step=ms, images_per_s_per_gpu=B / (T * ms * 1e-3), step_tflops_equiv=fl / (ms * 1e-3) / 1e12,
+                steps=steps, output_finite=finite,
+                eps_max_abs_diff_vs_exact_fp32=float((eps_split - eps_exact).abs().max().item()),
+                eps_max_abs=float(eps_exact.abs().max().item()),
+                note='opt-in plan option split_bf16=1; not used for `value`')
 
 
 def train_leg(dist, world, rank, dev, batch, steps, warmup):
@@ -205,6 +253,10 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE config: 16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary split_bf16 measurement')
+    ap.add_argument('--split-bf16', action='store_true',
+                    help='experiment: run the HEADLINE leg with the split_bf16 plan option (dtype is then reported as '
+                         '"f32 via 3xbf16 split MFMA"; the default is the exact-fp32 MFMA path)')
     ap.add_argument('--train-steps', type=int, default=10, help='0 disables the training leg')
     ap.add_argument('--train-batch', type=int, default=64, help='images per GPU (BASELINE config: 64)')
     a = ap.parse_args()
@@ -229,6 +281,8 @@ def main():
     netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], dev)
     netG.eval()
     netG.denoise_fn.plan.set_option('fuse_stats', 1)
+    if a.split_bf16:
+        netG.denoise_fn.plan.set_option('split_bf16', 1)
     B = a.batch
     torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
     cond = (torch.rand(B, 3, 128, 128, device=dev) * 2 - 1)
@@ -273,6 +327,12 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     images_per_s = world * B / (T * ms_per_step * 1e-3)
 
+    split = None
+    if rank == 0 and not a.no_split_leg and not a.split_bf16:
+        try:
+            split = split_bf16_leg(netG, st['cond'], T, dev)
+        except Exception as e:
+            split = {'error': '%s: %s' % (type(e).__name__, e)}
     train = None
     if a.train_steps > 0:
         # free the sampling state first (graph, workspace) -- the training workspace is ~18 GB at batch 64
@@ -288,7 +348,8 @@ def main():
         rec = {
             'metric': 'SR3 16->128 images/sec (2000-step sample)', 'value': images_per_s, 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 via 3xbf16 split MFMA' if a.split_bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'SR3 16->128 UNet (reference config/sr_sr3_16_128.json), batch %d per GPU, '
                                    '2000-step p_sample_loop via hipGraph replay; step = one reverse step of the batch; '
                                    'images/s = n_gpus*batch/(2000*t_step)' % B,
@@ -304,6 +365,8 @@ def main():
                 rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
             except Exception as e:
                 rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if split is not None:
+            rec['split_bf16'] = split
         if train is not None:
             rec['train'] = train
         if not a.no_cpu_baseline and world == 1:

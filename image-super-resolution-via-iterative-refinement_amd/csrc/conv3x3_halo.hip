@@ -29,18 +29,44 @@ namespace sr3 {
 __device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
 
-template <int WAVES_M, int WAVES_N, bool X2, bool DROP>
-__global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits): each residual is exact in fp32
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)v[e];
+    const float r1 = v[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+  }
+}
+
+// MODE 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  MODE 1 (opt-in, experimental): every fp32 operand is
+// split into three bf16 terms in the staging step and each product is evaluated as the six bf16 MFMA products
+// hh + hm + mh + mm + hl + lh (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the dropped terms are <= 2^-23 of
+// the product, i.e. fp32-class accuracy at 6/16 of the matrix-pipe time of the fp32 instruction.
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 : 1)
+void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
+  constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;     // 4 waves (two workgroups per CU) or 8 (one)
+  constexpr int RPP = NT / 8;                 // tile rows one loader pass covers (8 threads x float4 per row)
   constexpr int LDK = 36, BK = 32;
+  constexpr int LDB = 40;                     // MODE 1: bf16 row stride (32 + 8 pad), 80 bytes
+  constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;   // weight stages: the 4-wave MODE 1 tile single-buffers to keep two workgroups per CU
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
-  constexpr int BR = BN / 32;                 // weight loader rows per thread
+  constexpr int BR = BN / RPP;                // weight loader rows per thread
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
-  constexpr int HI = (HP_MAX * 8 + 255) / 256;   // halo float4 items per thread
+  constexpr int HI = (HP_MAX * 8 + NT - 1) / NT; // halo float4 items per thread
   constexpr int WSTAGE = BN * LDK;
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
-  float* halo = smem;                         // [HP][LDK]
-  float* wst = smem + HP_MAX * LDK;           // 2 x [BN][LDK]
+  float* halo = smem;                         // MODE 0: [HP][LDK]
+  float* wst = smem + HP_MAX * LDK;           // MODE 0: 2 x [BN][LDK]
+  __bf16* halo_b = reinterpret_cast<__bf16*>(smem_v);         // MODE 1: 3 planes x [HP_MAX][LDB]
+  __bf16* wst_b = halo_b + 3 * HP_MAX * LDB;                  // MODE 1: 3 planes x [BN][LDB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kq = tid & 7, lrow = tid >> 3;
@@ -68,13 +94,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   const bool do_x2 = X2 && (int)blockIdx.y == p.ksplit - 1;
 
   // ---- halo items of this thread (fixed for the whole kernel) --------------------------------
-  // item j covers halo pixel (tid >> 3) + 32 j, channel quad kq of the current chunk
+  // item j covers halo pixel (tid >> 3) + RPP j, channel quad kq of the current chunk
   int hpix[HI];        // source pixel index ((b*Hs + y)*Ws + x), or -1 when the tap falls in the padding
   int himg[HI];        // image slot within the tile (for the GN scale/shift select)
   const int TWp = g.TW + 2;
 #pragma unroll
   for (int j = 0; j < HI; ++j) {
-    const int hp = lrow + 32 * j;
+    const int hp = lrow + RPP * j;
     int pix = -1, nb = 0;
     if (hp < g.HP) {
       nb = hp / g.HPI;
@@ -129,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < HI; ++j) {
-      const int hp = lrow + 32 * j;
+      const int hp = lrow + RPP * j;
       if (hp < g.HP) {
         f32x4 v = rh[j];
         if (cur_act != 0) {
@@ -149,7 +175,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
           }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
-        *reinterpret_cast<f32x4*>(&halo[hp * LDK + kq * 4]) = v;
+        if constexpr (MODE == 0) {
+          *reinterpret_cast<f32x4*>(&halo[hp * LDK + kq * 4]) = v;
+        } else {
+          bf16x4 h, m, l;
+          split3(v, h, m, l);
+          *reinterpret_cast<bf16x4*>(&halo_b[(0 * HP_MAX + hp) * LDB + kq * 4]) = h;
+          *reinterpret_cast<bf16x4*>(&halo_b[(1 * HP_MAX + hp) * LDB + kq * 4]) = m;
+          *reinterpret_cast<bf16x4*>(&halo_b[(2 * HP_MAX + hp) * LDB + kq * 4]) = l;
+        }
       }
     }
   };
@@ -163,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
     const bool cvalid = c < CinS;
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const int n = tile_n * BN + lrow + 32 * j;
+      const int n = tile_n * BN + lrow + RPP * j;
       const bool ok = cvalid && n < p.Cout;
       wok[j] = ok;
       const int off = ok ? (n * ntap + tap) * CinS + c : 0;
@@ -172,10 +206,23 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   };
   auto store_w = [&](int stage) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    float* Bw = wst + stage * WSTAGE;
+    if constexpr (MODE == 0) {
+      float* Bw = wst + stage * WSTAGE;
 #pragma unroll
-    for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
+      for (int j = 0; j < BR; ++j)
+        *reinterpret_cast<f32x4*>(&Bw[(lrow + RPP * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
+    } else {
+      __bf16* Bb = wst_b + stage * 3 * BN * LDB;
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        bf16x4 h, m, l;
+        split3(wok[j] ? rw[j] : zero, h, m, l);
+        const int o = (lrow + RPP * j) * LDB + kq * 4;
+        *reinterpret_cast<bf16x4*>(&Bb[0 * BN * LDB + o]) = h;
+        *reinterpret_cast<bf16x4*>(&Bb[1 * BN * LDB + o]) = m;
+        *reinterpret_cast<bf16x4*>(&Bb[2 * BN * LDB + o]) = l;
+      }
+    }
   };
 
   // ---- MFMA fragments ---------------------------------------------------------------------------
@@ -201,6 +248,34 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int stage, int shift) {
+    if constexpr (MODE == 1) {
+      const __bf16* Bb = wst_b + stage * 3 * BN * LDB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {          // two K = 16 steps per 32-channel chunk
+        const int off = ks * 16 + (lane >> 5) * 8;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            a[i][pl] = *reinterpret_cast<const bf16x8*>(&halo_b[(pl * HP_MAX + hbase[i] + shift) * LDB + off]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[(pl * BN + brow + 32 * j) * LDB + off]);
+        // product-major order: four independent accumulators between dependent MFMAs; smallest terms first
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
     const float* Bw = wst + stage * WSTAGE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -239,13 +314,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
         if (more && !(p.dbg & 2)) load_w(SEG1{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
         const int fr = tap / 3, fs = tap - fr * 3;
         if (!(p.dbg & 1)) compute(stage, fr * TWp + fs);
-        if (more && !(p.dbg & 2)) store_w(stage ^ 1);
+        if constexpr (WST == 1) __syncthreads();    // single weight stage: every wave is done with it
+        if (more && !(p.dbg & 2)) store_w(stage ^ (WST - 1));
         if (last_tap && more_chunks && !(p.dbg & 2)) {
-          __syncthreads();                          // every wave is done reading the halo tile
+          if constexpr (WST == 2) __syncthreads();  // every wave is done reading the halo tile
           store_halo();
         }
         __syncthreads();
-        stage ^= 1;
+        stage ^= WST - 1;
       }
     }
   }
@@ -263,12 +339,13 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
         if (more) { load_halo(SEG2{}, chunk + 1); load_w(SEG2{}, chunk + 1, 0); }
         compute(stage, TWp + 1);
         if (more) {
-          store_w(stage ^ 1);
-          __syncthreads();
+          if constexpr (WST == 1) __syncthreads();
+          store_w(stage ^ (WST - 1));
+          if constexpr (WST == 2) __syncthreads();
           store_halo();
         }
         __syncthreads();
-        stage ^= 1;
+        stage ^= WST - 1;
       }
     }
   }
@@ -278,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
   __syncthreads();                                 // all MFMA reads of LDS are complete
   constexpr int LDT = 68;                          // 64 + 4 floats
   float* tr = smem + wave * (32 * LDT);
-  double* sred = reinterpret_cast<double*>(smem + 4 * 32 * LDT);   // [RB][BN][2] after the transpose regions
+  double* sred = reinterpret_cast<double*>(smem + NW * 32 * LDT);   // [RB][BN][2] after the transpose regions
   const bool direct = p.ksplit == 1;
   const size_t Mtot = (size_t)p.B * H * W;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
@@ -349,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
     const int rb_per_img = RB / g.NB;
     const int T = g.NB == 1 ? g.tiles_h * g.tiles_w : 1;
     const int tix = g.NB == 1 ? th_i * g.tiles_w + tw_i : 0;
-    for (int idx = tid; idx < BN * g.NB; idx += 256) {
+    for (int idx = tid; idx < BN * g.NB; idx += NT) {
       const int col = idx % BN, nb = idx / BN;
       const int nn = tile_n * BN + col;
       const int b = b0 + nb;
@@ -370,15 +447,17 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_halo(const ConvParams p, con
 namespace {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-template <int WAVES_M, int WAVES_N, bool X2, bool DROP>
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE>
 int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
-  constexpr int smem_main = (HP_MAX * 36 + 2 * BN * 36) * 4;
-  constexpr int smem_epi = 4 * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;
+  constexpr int smem_main = MODE == 0 ? (HP_MAX * 36 + 2 * BN * 36) * 4 : (3 * HP_MAX * 40 + WST * 3 * BN * 40) * 2;
+  constexpr int smem_epi = NW * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr_set = false;
-  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP>;
+  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP, MODE>;
   if (!attr_set) {
     SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -386,22 +465,22 @@ int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   const int tiles_n = (p.Cout + BN - 1) / BN;
   const int groups = (p.B + g.NB - 1) / g.NB;
   dim3 grid((unsigned)(tiles_n * g.tiles_w * g.tiles_h * groups), p.ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p, g);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, p, g);
   SR3_LAUNCH_CHECK("k_conv3x3_halo");
   return SR3_OK;
 }
 }  // namespace
 
-// cfg: 5 = 128(M) x 128(N) tile, 6 = 256 x 64 tile.  Returns false when the problem does not fit.
+// cfg: see halo_cfg_bm / _bn / _split in sr3_common.h.  Returns false when the problem does not fit.
 bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
-  if (p.ksize != 3 || p.stride != 1) return false;
+  if (p.ksize != 3 || p.stride != 1 || cfg < 5 || cfg > 10) return false;
   const int H = p.Ho, W = p.Wo;
-  const int BM = cfg == 6 ? 256 : 128;
+  const int BM = halo_cfg_bm(cfg);
   int TW, TH, NB;
   if (W >= 16) { TW = 16; TH = BM / 16; NB = 1; }
   else if (W == 8) { TW = 8; TH = 8; NB = BM / 64; }
   else return false;
-  if (cfg == 6 && W < 16) return false;
+  if (BM == 256 && W < 16) return false;
   if (H % TH || W % TW) return false;
   if (NB > 2) return false;
   g->TH = TH; g->TW = TW; g->NB = NB;
@@ -414,13 +493,32 @@ bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
 
 int halo_stats_slices(const HaloGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 1; }
 
-int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
+namespace {
+template <int WM, int WN, int MODE>
+int launch_halo_x(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   if (p.drop_thresh != 0) {       // train-mode block2 convs only
-    if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true, true>(p, g, st) : launch_halo<2, 2, true, true>(p, g, st);
-    return cfg == 6 ? launch_halo<4, 1, false, true>(p, g, st) : launch_halo<2, 2, false, true>(p, g, st);
+    if constexpr (MODE == 1 || WM * WN != 4) {
+      set_error("conv: this halo tile has no dropout instantiation");
+      return SR3_E_UNSUPPORTED;
+    } else {
+      return p.x2_w ? launch_halo<WM, WN, true, true, 0>(p, g, st) : launch_halo<WM, WN, false, true, 0>(p, g, st);
+    }
   }
-  if (p.x2_w) return cfg == 6 ? launch_halo<4, 1, true, false>(p, g, st) : launch_halo<2, 2, true, false>(p, g, st);
-  return cfg == 6 ? launch_halo<4, 1, false, false>(p, g, st) : launch_halo<2, 2, false, false>(p, g, st);
+  return p.x2_w ? launch_halo<WM, WN, true, false, MODE>(p, g, st) : launch_halo<WM, WN, false, false, MODE>(p, g, st);
+}
+}  // namespace
+
+int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
+  switch (cfg) {
+    case 5: return launch_halo_x<2, 2, 0>(p, g, st);
+    case 6: return launch_halo_x<4, 1, 0>(p, g, st);
+    case 7: return launch_halo_x<2, 2, 1>(p, g, st);    // opt-in 3 x bf16 split MFMA (inference only)
+    case 8: return launch_halo_x<4, 1, 1>(p, g, st);
+    case 9: return launch_halo_x<4, 2, 0>(p, g, st);    // 8 waves, one workgroup per CU
+    case 10: return launch_halo_x<4, 2, 1>(p, g, st);
+  }
+  set_error("conv: bad halo tile_cfg %d", cfg);
+  return SR3_E_BADARG;
 }
 
 }  // namespace sr3

@@ -332,6 +332,9 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     HaloGeom g;
     if (p.ksize == 3 && p.stride == 1) {
       if (p.Cout <= 64 && halo_geometry(p, 6, &g)) tile_cfg = 6;
+      else if (p.Cout > 64 && halo_geometry(p, 9, &g) &&
+               (long)cdiv(p.Cout, 128) * g.tiles_w * g.tiles_h * cdiv(p.B, g.NB) >= 256)
+        tile_cfg = 9;     // 8-wave 256x128 tile: half the weight traffic, when it still fills every CU
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
     }
   }
@@ -353,7 +356,7 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     if (tile_cfg >= 5) {
       HaloGeom g;
       if (!halo_geometry(p, tile_cfg, &g)) { ksplit = 1; return; }
-      const int bn = tile_cfg == 6 ? 64 : 128;
+      const int bn = halo_cfg_bn(tile_cfg);
       tiles = (long)cdiv(p.Cout, bn) * g.tiles_w * g.tiles_h * cdiv(p.B, g.NB);
       units = nchunks; min_units = 2;
     } else {
@@ -364,9 +367,12 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     int ks = 1;
     // split K until the grid gives ~2 workgroups per CU (in-run A/B on MI355X: threshold 384 -> 14.87 ms per
     // step, 256 -> 14.96 ms; SR3_KSPLIT_TILES overrides)
-    static const long split_below = getenv("SR3_KSPLIT_TILES") ? atol(getenv("SR3_KSPLIT_TILES")) : 384;
+    static const long split_below_env = getenv("SR3_KSPLIT_TILES") ? atol(getenv("SR3_KSPLIT_TILES")) : 384;
+    // the 8-wave tiles run one workgroup per CU: one full round of 256 is the target there
+    const bool wide = tile_cfg >= 9;
+    const long split_below = wide ? 256 : split_below_env;
     if (tiles < split_below) {
-      ks = (int)((512 + tiles - 1) / tiles);
+      ks = (int)(((wide ? 256 : 512) + tiles - 1) / tiles);
       const int cap = units / min_units > 1 ? units / min_units : 1;
       if (ks > cap) ks = cap;
       if (ks > 16) ks = 16;
@@ -435,7 +441,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   if (p.x2_w && ((p.x2_C0 & 3) || (p.x2_C1 & 3) || !p.x2_src0 || (p.x2_C1 > 0 && !p.x2_src1))) { set_error("conv: bad x2 segment"); return SR3_E_BADARG; }
   if (tile_cfg >= 5) {
     HaloGeom g;
-    if (tile_cfg > 6 || !halo_geometry(p, tile_cfg, &g)) { set_error("conv: halo tile_cfg %d does not fit this problem", tile_cfg); return SR3_E_UNSUPPORTED; }
+    if (tile_cfg > 10 || !halo_geometry(p, tile_cfg, &g)) { set_error("conv: halo tile_cfg %d does not fit this problem", tile_cfg); return SR3_E_UNSUPPORTED; }
     const int nchunks = cdiv(Cin, 32);
     if ((long)(ksplit - 1) * cdiv(nchunks, ksplit) >= nchunks && ksplit > 1) { set_error("conv: ksplit %d leaves an empty split over %d chunks", ksplit, nchunks); return SR3_E_BADARG; }
     rc = conv3x3_halo_forward(p, tile_cfg, g, st);

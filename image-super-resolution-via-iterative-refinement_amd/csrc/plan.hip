@@ -372,7 +372,17 @@ struct Builder {
     o.tile_cfg = P->tile_cfg; o.ksplit = P->ksplit;
     o.ss_rel = act_mode ? cur_ss : 0;
     o.has_drop = train && drop_key >= 0; o.drop_key = (unsigned)(drop_key >= 0 ? drop_key : 0);
+    // opt-in: the 3 x bf16 split MFMA instantiation of the 8-wave tile wherever it fits (inference plans only)
+    {
+      HaloGeom sg;
+      if (P->split_bf16 && !train && o.tile_cfg == 0 && ksize == 3 && stride == 1 && Cout > 64 && halo_geometry(c, 10, &sg))
+        o.tile_cfg = 10;
+    }
     conv_pick(c, o.tile_cfg, o.ksplit);
+    if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
+      o.tile_cfg = 5; o.ksplit = P->ksplit;
+      conv_pick(c, o.tile_cfg, o.ksplit);
+    }
     // the 256x64 dropout instantiation spills registers but still beats the half-empty 128x128 tile on the
     // 64-channel layers (A/B on MI355X: 219.7 vs 222.2 ms per step); SR3_DROP_CFG5 forces the latter
     static const bool use5 = getenv("SR3_DROP_CFG5") != nullptr;
@@ -380,6 +390,12 @@ struct Builder {
       o.tile_cfg = 5; o.ksplit = P->ksplit;
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
+    // opt-in: run the halo-tile convs on the 3 x bf16 split MFMA instantiations (inference plans only)
+    // (the 256x64 split instantiation spills and loses to its fp32 twin, so Cout <= 64 layers stay on tile 6)
+    // split_bf16 = 2 maps tile 6 -> 8 as well (tests / experiments)
+    if (P->split_bf16 && !train && o.tile_cfg == 5) o.tile_cfg = 7;
+    else if (P->split_bf16 && !train && o.tile_cfg == 9) o.tile_cfg = 10;
+    else if (P->split_bf16 >= 2 && !train && o.tile_cfg == 6) o.tile_cfg = 8;
     if (train) {
       Rec r;
       r.kind = R_CONV; r.x0 = x0; r.x1 = x1; r.out = out; r.r0 = r0; r.r1 = r1; r.q0 = q0; r.q1 = q1;
@@ -845,6 +861,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "ksplit")) slot = &plan->ksplit;
   else if (!strcmp(key, "keep_all")) slot = &plan->keep_all;
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
+  else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
   *slot = value;
@@ -922,7 +939,12 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
       float red_ms = -1.f;
       if (o.kind == OP_CONV) {
         // 51-54 im2col kernel tile configs; 55/56 halo-tile 3x3 kernel (57/58: with the fused 1x1 segment)
-        kind += o.tile_cfg + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
+        //        155-158: the same four on the opt-in split-bf16 instantiations; 255/257: the 8-wave 256x128 tile
+        //        (cfg 9), 355/357: its split-bf16 twin (cfg 10)
+        {
+          static const int base[11] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305};
+          kind += base[o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
+        }
         const ConvParams& c = o.cp;
         fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)(c.C0 + c.C1) * c.ksize * c.ksize + (o.has_x2 ? c.x2_C0 + c.x2_C1 : 0));
         if (o.ksplit > 1) {      // split the op into its GEMM kernel and its split-K reduce kernel

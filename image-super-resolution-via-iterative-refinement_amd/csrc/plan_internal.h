@@ -99,7 +99,7 @@ struct sr3_plan {
   size_t fin_gn_w = 0, fin_gn_b = 0, fin_w = 0, fin_b = 0;
   int fin_cin = 0, out_ch = 0;
   // options
-  int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0;
+  int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
   // compiled forward
   int built_batch = -1;
   int built_cond = -1;

@@ -70,6 +70,7 @@ class Plan(object):
         rc = self.lib.sr3_plan_set_option(self.handle, key.encode(), int(value))
         if rc < 0:
             L.check(rc)
+        self.__dict__.setdefault('options', {})[key] = int(value)
         return rc
 
     def workspace_bytes(self, batch):

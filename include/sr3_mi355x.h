@@ -77,7 +77,13 @@ size_t sr3_plan_param_floats(const sr3_plan* plan);
 int sr3_plan_num_ops(sr3_plan* plan, int batch);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
-/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all"}; returns previous value */
+/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16"};
+ * returns previous value.
+ * split_bf16 (default 0, experimental): run the halo-tile 3x3 convolutions of the inference plan on
+ *   v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (x = h + m + l) and the six
+ *   products hh, hm, mh, mm, hl, lh accumulated in fp32 -- fp32-class accuracy (dropped terms <= 2^-23 of a
+ *   product), not the bit pattern of the fp32 MFMA.  Operands are split while they are staged into LDS (a pre-split
+ *   weight copy was measured slower: 1.5x the L2->LDS bytes). */
 int sr3_plan_set_option(sr3_plan* plan, const char* key, int value);
 
 /* Debug taps: where each top-level layer output (downs.i / mid.i / ups.i, NHWC) lives inside the

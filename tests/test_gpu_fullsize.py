@@ -58,6 +58,12 @@ def test_fullsize_forward_and_step_vs_oracle(name):
         ref = O.unet_forward(sd, desc, x, t)
     got = netG.denoise_fn(x.to(d), t.to(d)).cpu()
     err = G.assert_close(got, ref, what=name + ' eps')
+    if name == 'sr3_16_128':       # opt-in 3 x bf16 split MFMA path: same stated tolerance
+        netG.denoise_fn.plan.set_option('split_bf16', 1)
+        got_s = netG.denoise_fn(x.to(d), t.to(d)).cpu()
+        err_s = G.assert_close(got_s, ref, what=name + ' eps (split_bf16)')
+        print('%s: split_bf16 eps max abs err %.2e (exact-fp32 path %.2e)' % (name, err_s, err))
+        netG.denoise_fn.plan.set_option('split_bf16', 0)
     # one reverse step with injected noise through the public p_sample
     tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
     xs = torch.randn(1, 3, S, S, generator=g)

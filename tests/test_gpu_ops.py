@@ -65,7 +65,7 @@ def _make_case(case, seed=1):
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2), (5, 1), (6, 1), (5, 2),
-                                             (6, 2)])
+                                             (6, 2), (7, 1), (8, 1), (7, 2), (9, 1), (10, 1), (9, 2), (10, 3)])
 def test_conv(case, tile_cfg, ksplit):
     src0, src1, w, kw = _make_case(case)
     total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]
@@ -83,7 +83,7 @@ def test_conv(case, tile_cfg, ksplit):
 
 
 @pytest.mark.parametrize('ksplit', [1, 2])
-@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6])
+@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6, 9, 10])
 @pytest.mark.parametrize('case', [('stats8', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True),
                                   ('stats32', 2, 32, 32, 32, 32, 160, 3, 1, 0, 2, True, True, True),
                                   ('stats_up', 2, 32, 0, 16, 16, 64, 3, 1, 1, 0, False, False, True)],
@@ -111,7 +111,7 @@ def test_conv_fused_output_stats(ksplit, tile_cfg, case):
     assert torch.allclose(st[:, :, 1], s2, rtol=1e-9, atol=1e-9)
 
 
-@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (5, 1), (6, 1), (5, 2), (6, 3)])
+@pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (5, 1), (6, 1), (5, 2), (6, 3), (7, 1), (8, 1), (9, 1), (10, 1), (9, 2)])
 @pytest.mark.parametrize('shape', [(2, 64, 0, 16, 16, 128, 96, 32), (3, 32, 0, 8, 8, 64, 24, 8), (1, 128, 0, 32, 32, 64, 192, 0)],
                          ids=['16x16', '8x8_oddB', '32x32'])
 def test_block_conv_with_fused_res_conv(shape, tile_cfg, ksplit):

@@ -49,6 +49,29 @@ def test_unet_forward_and_layer_taps(name, fuse):
 
 
 @pytest.mark.parametrize('name', NAMES)
+def test_unet_forward_split_bf16_option(name):
+    """Opt-in `split_bf16` plan option (3 x bf16 operand split on the bf16 MFMA): same stated tolerance."""
+    m, g, sd = build(name, split_bf16=2)       # 2: every halo-tile conv, including the Cout <= 64 ones
+    un = m.netG.denoise_fn
+    d = G.dev()
+    eps = un(torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d))
+    G.assert_close(eps.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (split_bf16)')
+    # the reverse loop, eager and graph replay
+    cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']).to(d)
+    x_T = torch.from_numpy(g['loop/x_T']).to(d)
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    r = m.netG.p_sample_loop(sr if cond else tuple(x_T.shape), continous=True, x_T=x_T, noise_seq=zs)
+    G.assert_close(r.cpu(), torch.from_numpy(g['loop/ret_continous']), tol=1e-4, what=name + ' loop (split_bf16)')
+    outs = []
+    for use_graph in (False, True):
+        m.netG.use_graph = use_graph
+        torch.manual_seed(7)
+        outs.append(m.netG.p_sample_loop(sr if cond else tuple(x_T.shape), continous=False).clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('name', NAMES)
 def test_unet_forward_buffer_reuse_matches(name):
     """The liveness-planned workspace (buffers recycled) gives the same eps as keep_all."""
     m, g, sd = build(name)

@@ -81,7 +81,7 @@ def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2
                         continue
                     if cfg >= 5 and ks > 1 and ks * 2 > (Cin + 31) // 32:
                         continue
-                    bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 128), 6: (256, 64)}[cfg]
+                    bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 128), 6: (256, 64), 7: (128, 128), 8: (256, 64), 9: (256, 128), 10: (256, 128)}[cfg]
                     tiles = -(-B * Ho * Ho // bm) * -(-Cout // bn)
                     if ks > 1 and tiles * ks > 4096:
                         continue
@@ -105,10 +105,12 @@ def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2
             del s0, s1, w, out, ss
 
 
-def unet_time(B, out_path, fuse):
+def unet_time(B, out_path, fuse, split_bf16=0):
     d = torch.device('cuda:0')
     plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
     plan.set_option('fuse_stats', fuse)
+    plan.set_option('split_bf16', split_bf16)
+    torch.manual_seed(0)
     arena = torch.randn(plan.param_floats, device=d) * 0.02
     freq = plan.default_freq().to(d)
     ws = E.Workspace()
@@ -123,11 +125,62 @@ def unet_time(B, out_path, fuse):
         fn()
     msg = time_fn(g.replay, warm=2, iters=5)
     fl = plan.forward_flops(B)
-    rec = dict(what='unet_forward', B=B, fuse_stats=fuse, ms_eager=ms, ms_graph=msg, tflops_graph=fl / msg / 1e9,
+    ref = getattr(unet_time, '_ref', None)
+    err = None
+    if ref is not None and ref.shape == out.shape:
+        err = float((out - ref).abs().max() / ref.abs().max())
+    else:
+        unet_time._ref = out.clone()
+    rec = dict(what='unet_forward', B=B, fuse_stats=fuse, split_bf16=split_bf16, rel_err_vs_first=err, ms_eager=ms, ms_graph=msg, tflops_graph=fl / msg / 1e9,
                ops=plan.num_ops(B), ws_gb=plan.workspace_bytes(B) / 1e9, finite=bool(torch.isfinite(out).all()))
     with open(out_path, 'a') as f:
         f.write(json.dumps(rec) + '\n')
     print(rec, flush=True)
+
+
+def op_compare(B, out_path, reps=3):
+    """Per-op HIP-event times of one forward: exact-fp32 plan vs split_bf16 plan, side by side."""
+    import ctypes as C
+    from sr3_hip import lib as L
+    lib = L.load()
+    d = torch.device('cuda:0')
+    res = {}
+    for mode in (0, 1):
+        plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+        plan.set_option('split_bf16', mode)
+        torch.manual_seed(0)
+        arena = torch.randn(plan.param_floats, device=d) * 0.02
+        freq = plan.default_freq().to(d)
+        x = torch.randn(B, 3, 128, 128, device=d)
+        cond = torch.randn(B, 3, 128, 128, device=d)
+        lvl = torch.full((B,), 0.5, device=d)
+        out = torch.empty(B, 3, 128, 128, device=d)
+        need = plan.workspace_bytes(B)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=d)
+        wsp = ws.data_ptr() + (-ws.data_ptr()) % 256
+        n = C.c_int()
+        ms = (C.c_float * 4096)(); kind = (C.c_int * 4096)(); fl = (C.c_double * 4096)()
+        acc = None
+        for r in range(reps + 1):
+            L.check(lib.sr3_unet_forward_profile(plan.handle, L.ptr(x), L.ptr(cond), 3, L.ptr(lvl), None, L.ptr(freq),
+                                                 L.ptr(arena), C.c_void_p(wsp), need, L.ptr(out), B,
+                                                 C.c_void_p(torch.cuda.current_stream().cuda_stream), 4096, ms, kind, fl,
+                                                 C.byref(n)))
+            if r == 0:
+                acc = [0.0] * n.value
+                continue
+            for i in range(n.value):
+                acc[i] += ms[i] / reps
+        res[mode] = [(kind[i], fl[i], acc[i]) for i in range(n.value)]
+    with open(out_path, 'w') as f:
+        tot = [0.0, 0.0]
+        for (k0, f0, m0), (k1, f1, m1) in zip(res[0], res[1]):
+            tot[0] += m0; tot[1] += m1
+            if k0 != k1:
+                f.write('%4d %4d gflop %8.2f  fp32 %7.1f us %6.1f TF | split %7.1f us %6.1f TF  x%.2f\n' % (
+                    k0, k1, f0 / 1e9, m0 * 1e3, f0 / max(m0, 1e-9) / 1e9, m1 * 1e3, f1 / max(m1, 1e-9) / 1e9, m0 / max(m1, 1e-9)))
+        f.write('total fp32 %.3f ms split %.3f ms\n' % (tot[0], tot[1]))
+    print(open(out_path).read(), flush=True)
 
 
 def unet_time_split(B, nsplit, out_path):
@@ -244,11 +297,14 @@ if __name__ == '__main__':
     ap.add_argument('--tag', default='')
     ap.add_argument('--split', default='')
     ap.add_argument('--configs', action='store_true')
+    ap.add_argument('--opcmp', action='store_true')
     ap.add_argument('--train', default='')
     a = ap.parse_args()
     if a.train:
         for bb in [int(v) for v in a.train.split(',')]:
             train_time(bb, os.path.join(OUT, 'probe_train.jsonl'))
+    if a.opcmp:
+        op_compare(a.batch, os.path.join(OUT, 'probe_opcmp.txt'))
     if a.configs:
         config_times(os.path.join(OUT, 'probe_configs.jsonl'))
     if a.split:
@@ -257,6 +313,7 @@ if __name__ == '__main__':
     if a.unet:
         for fuse in (0, 1):
             unet_time(a.batch, os.path.join(OUT, 'probe_unet.jsonl'), fuse)
+        unet_time(a.batch, os.path.join(OUT, 'probe_unet.jsonl'), 1, split_bf16=1)
     if a.sweep:
         conv_sweep(a.batch, os.path.join(OUT, 'probe_conv_B%d%s.jsonl' % (a.batch, a.tag)), a.quick,
                    only=[x for x in a.only.split(',') if x] or None, cfgs=[int(x) for x in a.cfgs.split(',')],
