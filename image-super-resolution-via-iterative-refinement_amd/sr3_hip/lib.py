@@ -30,8 +30,17 @@ _P = C.c_void_p
 _I = C.c_int
 _Z = C.c_size_t
 
-# name -> (restype, argtypes): every symbol include/sr3_mi355x.h declares
+# name -> (restype, argtypes): every symbol include/sr3_mi355x.h and include/sr3_io_mi355x.h declare
+_F = C.c_float
+_PI = C.POINTER(C.c_int)
 SIGNATURES = {
+    'sr3_tensor2img': (_I, [_P, _I, _I, _I, _I, _F, _F, _I, _I, _I, _P, _PI, _PI, _PI, _P]),
+    'sr3_sse_u8': (_I, [_P, _P, _I, _Z, _P, _P]),
+    'sr3_ssim_scratch_bytes': (_Z, [_I, _I, _I, _I]),
+    'sr3_ssim_u8': (_I, [_P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    'sr3_eval_scratch_bytes': (_Z, [_I, _I, _I, _I]),
+    'sr3_eval_psnr_ssim_f32': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P, _P]),
+    'sr3_images_u8_to_f32': (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _P, _P]),
     'sr3_version': (_I, []),
     'sr3_last_error': (C.c_char_p, []),
     'sr3_plan_create': (_I, [C.POINTER(UnetDesc), C.POINTER(_P)]),

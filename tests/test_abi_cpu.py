@@ -1,5 +1,5 @@
 """CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/sr3_mi355x.h
-declares, the plan's parameter table is the reference's state-dict schema, and the drop-in package
+and include/sr3_io_mi355x.h declare, the plan's parameter table is the reference's state-dict schema, and the drop-in package
 round-trips checkpoints and reproduces the reference's initialisation order."""
 import os
 import re
@@ -11,9 +11,12 @@ from helpers import DESCS, ROOT, load_golden, opt_for
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, 'include', 'sr3_mi355x.h')).read()
-    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(sr3_[a-z0-9_]+)\s*\(', src)))
+    syms = set()
+    for h in ('sr3_mi355x.h', 'sr3_io_mi355x.h'):
+        src = open(os.path.join(ROOT, 'include', h)).read()
+        src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+        syms |= set(re.findall(r'\b(sr3_[a-z0-9_]+)\s*\(', src))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():

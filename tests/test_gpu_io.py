@@ -1,0 +1,167 @@
+"""GPU parity of the steps either side of the hot path through include/sr3_io_mi355x.h:
+tensor2img / PSNR / SSIM (drop-in core/metrics.py) and transform_augment / the device-side batch loader (drop-in
+data/) against the reference-generated vectors (tests/golden/io_metrics.npz) and the numpy oracle.
+Bars: uint8 images and the PSNR reduction bit-exact; fp32 transform outputs bit-exact; SSIM rel 1e-10 (double, a
+different but fixed summation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import ROOT                              # noqa: E402
+from oracle import io_metrics_oracle as O             # noqa: E402
+from test_oracle_io import _write_triplets             # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def g():
+    return dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'io_metrics.npz')))
+
+
+def test_tensor2img_golden(g):
+    import core.metrics as M
+    x = torch.from_numpy(g['t2i/x'])
+    gray = torch.from_numpy(g['t2i/gray_x'])
+    cases = [('single', x[:1], {}), ('chw', x[2], {}), ('grid5', x, {}), ('grid4_01', x[:4], dict(min_max=(0, 1))),
+             ('gray_grid', gray, {}), ('gray_2d', gray[:1], {})]
+    for key, t, kw in cases:
+        for dev in ('cpu', 'cuda'):
+            got = M.tensor2img(t.to(dev), **kw)
+            assert got.dtype == np.uint8 and got.shape == g['t2i/' + key].shape, key
+            assert np.array_equal(got, g['t2i/' + key]), key
+    f = M.tensor2img(x[:1], out_type=np.float32)
+    assert f.dtype == np.float32 and np.array_equal(f, g['t2i/float_single'])
+    d = M.tensor2img_device(x[:1].cuda())
+    assert d.is_cuda and d.dtype == torch.uint8
+    with pytest.raises(TypeError):
+        M.tensor2img(torch.zeros(2, 2, 2, 2, 2))
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 128, 128), (16, 3, 128, 128), (7, 3, 33, 17), (9, 1, 20, 24), (1, 1, 64, 64), (2, 3, 512, 512)])
+def test_tensor2img_vs_oracle(shape):
+    import core.metrics as M
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=gen) * 0.7
+    got = M.tensor2img(x.cuda())
+    ref = O.tensor2img(x.numpy())
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_psnr_ssim_golden(g):
+    import core.metrics as M
+    a, b = g['m/a'], g['m/b']
+    assert M.calculate_psnr(a, b) == float(g['m/psnr'])                    # exact: integer SSE, same final expression
+    assert M.calculate_psnr(a, a) == float('inf')
+    assert M.calculate_ssim(a, b) == pytest.approx(float(g['m/ssim3']), rel=1e-10)
+    assert M.calculate_ssim(a[:, :, :1], b[:, :, :1]) == pytest.approx(float(g['m/ssim1']), rel=1e-10)
+    assert M.calculate_ssim(a[:, :, 0], b[:, :, 0]) == pytest.approx(float(g['m/ssim2d']), rel=1e-10)
+    assert M.calculate_psnr(g['m/n'], g['m/s']) == float(g['m/psnr_sn'])
+    assert M.calculate_ssim(g['m/n'], g['m/s']) == pytest.approx(float(g['m/ssim_sn']), rel=1e-10)
+    with pytest.raises(ValueError):
+        M.calculate_ssim(a, b[:-1])
+    with pytest.raises(TypeError):
+        M.calculate_psnr(a.astype(np.float64), b.astype(np.float64))
+    with pytest.raises(ValueError):
+        M.calculate_ssim(a[:8, :8], b[:8, :8])
+
+
+@pytest.mark.parametrize('hw', [(128, 128), (11, 11), (37, 50), (512, 512)])
+def test_psnr_ssim_vs_oracle(hw):
+    import core.metrics as M
+    rng = np.random.RandomState(hw[0] * 7 + hw[1])
+    a = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.randint(-30, 31, size=a.shape), 0, 255).astype(np.uint8)
+    assert M.calculate_psnr(a, b) == O.calculate_psnr(a, b)
+    assert M.calculate_ssim(a, b) == pytest.approx(O.calculate_ssim(a, b), rel=1e-10)
+    # device tensors in, nothing but the scalar out
+    assert M.calculate_psnr(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) == O.calculate_psnr(a, b)
+
+
+def test_fused_validation_metrics_batch():
+    """sr.py:119-145 per-image chain for a whole (16, 3, 128, 128) batch: one call, 2 scalars per image back."""
+    import core.metrics as M
+    gen = torch.Generator().manual_seed(9)
+    hr = (torch.rand(16, 3, 128, 128, generator=gen) * 2 - 1)
+    sr = (hr + 0.08 * torch.randn(16, 3, 128, 128, generator=gen))        # leaves [-1, 1]: exercises the clamp
+    sr[3] = hr[3]                                                            # identical pair -> inf
+    psnr, ssim = M.psnr_ssim_batch(sr.cuda(), hr.cuda())
+    assert len(psnr) == 16 and len(ssim) == 16
+    for i in range(16):
+        a = O.tensor2img(sr[i].numpy())
+        b = O.tensor2img(hr[i].numpy())
+        assert psnr[i] == O.calculate_psnr(a, b), i
+        assert ssim[i] == pytest.approx(O.calculate_ssim(a, b), rel=1e-10), i
+    assert psnr[3] == float('inf') and ssim[3] == pytest.approx(1.0, rel=1e-12)
+    p1, s1 = M.psnr_ssim_batch(sr[5], hr[5])                                 # 3-D (C, H, W) inputs, host tensors
+    assert p1 == [psnr[5]] and s1 == [ssim[5]]
+
+
+def test_transform_augment_golden_and_oracle(g):
+    import data.util as U
+    imgs = [g['tr/in0'], g['tr/in1']]
+    r = U.transform_augment(imgs, split='val', min_max=(-1, 1))
+    assert r[0].is_cuda and r[0].dtype == torch.float32 and tuple(r[0].shape) == (3, 8, 9)
+    assert np.array_equal(r[0].cpu().numpy(), g['tr/val0']) and np.array_equal(r[1].cpu().numpy(), g['tr/val1'])
+    u8 = torch.from_numpy(np.stack(imgs, 0))
+    out = U.u8_batch_to_f32(u8, [True, True], (-1, 1))
+    assert np.array_equal(out[0].cpu().numpy(), g['tr/train_flip0']) and np.array_equal(out[1].cpu().numpy(), g['tr/train_flip1'])
+    out = U.u8_batch_to_f32(u8, [False, True], (0, 1))
+    assert np.array_equal(out[0].cpu().numpy(), g['tr/train_noflip01_0'])
+    assert np.array_equal(out[1].cpu().numpy(), O.transform_augment([imgs[1]], 'train', (0, 1), flip=True)[0])
+    # split 'train': the pair is flipped together or not at all
+    torch.manual_seed(4)
+    seen = set()
+    for _ in range(12):
+        r = U.transform_augment(imgs, split='train', min_max=(-1, 1))
+        f0 = np.array_equal(r[0].cpu().numpy(), g['tr/train_flip0'])
+        f1 = np.array_equal(r[1].cpu().numpy(), g['tr/train_flip1'])
+        assert f0 == f1
+        assert f0 or np.array_equal(r[0].cpu().numpy(), g['tr/val0'])
+        seen.add(f0)
+    assert seen == {True, False}
+    # every byte value, full size
+    big = torch.arange(256, dtype=torch.uint8).repeat(3 * 128 * 128 * 4 // 256).view(4, 128, 128, 3)
+    got = U.u8_batch_to_f32(big, [True, False, True, False], (-1, 1)).cpu().numpy()
+    for i in range(4):
+        assert np.array_equal(got[i], O.transform_augment([big[i].numpy()], 'train', (-1, 1), flip=(i % 2 == 0))[0])
+
+
+def test_device_batches_feed_the_model(tmp_path):
+    """create_dataset -> create_dataloader -> DDPM.feed_data: the batch dict is the reference's, already on the GPU."""
+    import data as Data
+    from PIL import Image
+    root = str(tmp_path / 'ds')
+    _write_triplets(root, 6, l=16, r=32)
+    opt = dict(name='t', mode='HR', dataroot=root, datatype='img', l_resolution=16, r_resolution=32, data_len=-1,
+               batch_size=4, use_shuffle=False, num_workers=0)
+    ds = Data.create_dataset(opt, 'train')
+    torch.manual_seed(21)
+    batches = list(Data.create_dataloader(ds, opt, 'train'))
+    assert len(batches) == 2 and set(batches[0]) == {'HR', 'SR', 'Index'}
+    assert tuple(batches[0]['HR'].shape) == (4, 3, 32, 32) and batches[0]['HR'].is_cuda and batches[1]['SR'].shape[0] == 2
+    assert batches[0]['Index'].tolist() == [0, 1, 2, 3]
+    k = 0
+    flips = []
+    for bt in batches:
+        for j in range(bt['HR'].shape[0]):
+            flag = {}
+            for key, sub in (('HR', 'hr_32'), ('SR', 'sr_16_32')):
+                img = np.asarray(Image.open(os.path.join(root, sub, '%05d.png' % k)).convert('RGB'))
+                got = bt[key][j].cpu().numpy()
+                hits = [f for f in (False, True) if np.array_equal(got, O.transform_augment([img], 'train', (-1, 1), flip=f)[0])]
+                assert len(hits) == 1, (k, key)
+                flag[key] = hits[0]
+            assert flag['HR'] == flag['SR'], k            # one draw per sample, shared by the pair
+            flips.append(flag['HR'])
+            k += 1
+    assert len(flips) == 6
+    # phase 'val': batch 1, LR included, no flips
+    vopt = dict(opt, mode='LRHR')
+    vds = Data.create_dataset(vopt, 'val')
+    vb = next(iter(Data.create_dataloader(vds, vopt, 'val')))
+    assert set(vb) == {'HR', 'SR', 'LR', 'Index'} and tuple(vb['LR'].shape) == (1, 3, 16, 16)
+    img = np.asarray(Image.open(os.path.join(root, 'lr_16', '00000.png')).convert('RGB'))
+    assert np.array_equal(vb['LR'][0].cpu().numpy(), O.transform_augment([img], 'val', (-1, 1))[0])

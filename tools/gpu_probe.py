@@ -183,6 +183,46 @@ def op_compare(B, out_path, reps=3):
     print(open(out_path).read(), flush=True)
 
 
+def io_times(out_path):
+    """HBM-bound helpers either side of the path: time and effective bandwidth."""
+    import core.metrics as M
+    import data.util as U
+    d = torch.device('cuda:0')
+    recs = []
+    for (B, S) in ((64, 128), (256, 128), (16, 512), (64, 512)):
+        u8 = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, device=d)
+        flip = torch.randint(0, 2, (B,), dtype=torch.uint8, device=d)
+        out = torch.empty(B, 3, S, S, device=d)
+        ms = time_fn(lambda: U.u8_batch_to_f32(u8, flip, (-1, 1), d, out=out), warm=3, iters=20)
+        by = B * S * S * 3 * 5
+        recs.append(dict(what='images_u8_to_f32', B=B, S=S, us=ms * 1e3, algorithmic_bytes=by, GBps=by / ms / 1e6))
+        x = torch.randn(B, 3, S, S, device=d)
+        y = (x + 0.05 * torch.randn_like(x))
+        lib = L.load()
+        nb = int(lib.sr3_eval_scratch_bytes(B, 3, S, S))
+        scratch = torch.empty(nb + 256, dtype=torch.uint8, device=d)
+        sse = torch.empty(B, dtype=torch.int64, device=d)
+        ssim = torch.empty(B, dtype=torch.float64, device=d)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        off = (-scratch.data_ptr()) % 256
+
+        def ev():
+            L.check(lib.sr3_eval_psnr_ssim_f32(L.ptr(x), L.ptr(y), B, 3, S, S, -1.0, 1.0, C.c_void_p(scratch.data_ptr() + off), nb,
+                                               L.ptr(sse), L.ptr(ssim), st))
+        ms = time_fn(ev, warm=3, iters=20)
+        by = B * S * S * 3 * 8          # two fp32 images read once
+        fl = B * (S - 10) * (S - 10) * 3 * 121 * 10.0
+        recs.append(dict(what='eval_psnr_ssim_f32', B=B, S=S, us=ms * 1e3, algorithmic_bytes=by, GBps=by / ms / 1e6,
+                         f64_gflops=fl / ms / 1e6))
+        t = time_fn(lambda: M.tensor2img_device(x), warm=3, iters=20)
+        by = B * S * S * 3 * 5
+        recs.append(dict(what='tensor2img(grid)', B=B, S=S, us=t * 1e3, algorithmic_bytes=by, GBps=by / t / 1e6))
+    with open(out_path, 'w') as f:
+        for r in recs:
+            f.write(json.dumps(r) + '\n')
+            print(r, flush=True)
+
+
 def unet_time_split(B, nsplit, out_path):
     """One forward of B images as `nsplit` independent graph branches of B/nsplit images each."""
     d = torch.device('cuda:0')
@@ -298,11 +338,14 @@ if __name__ == '__main__':
     ap.add_argument('--split', default='')
     ap.add_argument('--configs', action='store_true')
     ap.add_argument('--opcmp', action='store_true')
+    ap.add_argument('--io', action='store_true')
     ap.add_argument('--train', default='')
     a = ap.parse_args()
     if a.train:
         for bb in [int(v) for v in a.train.split(',')]:
             train_time(bb, os.path.join(OUT, 'probe_train.jsonl'))
+    if a.io:
+        io_times(os.path.join(OUT, 'probe_io.jsonl'))
     if a.opcmp:
         op_compare(a.batch, os.path.join(OUT, 'probe_opcmp.txt'))
     if a.configs:
