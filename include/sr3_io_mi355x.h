@@ -1,9 +1,10 @@
-/* sr3_io_mi355x.h -- C ABI of the steps either side of the SR3 hot path (SURVEY.md 8f rows 2 and 3), exported by
+/* sr3_io_mi355x.h -- C ABI of the steps either side of the SR3 hot path (SURVEY.md 8f rows 2, 3 and 4), exported by
  * the same libsr3_mi355x.so as include/sr3_mi355x.h (error codes, sr3_last_error() and the pointer / stream
  * conventions are the ones defined there: device pointers, asynchronous on `stream`, no allocation inside).
  *
  *   before the path: data/util.py:76-83 transform_augment (ToTensor, shared horizontal flip, range map), which
  *                    data/LRHR_dataset.py:92-99 applies to every sample of a batch
+ *                    data/prepare_data.py:17-40 resize_multiple (the bicubic LR / HR / SR triplet a sample is made of)
  *   after the path : core/metrics.py:8-34 tensor2img, :43-50 calculate_psnr, :53-93 ssim / calculate_ssim, as used by
  *                    sr.py:119-145,188-196, infer.py:73-92 and eval.py on the tensors DDPM.get_current_visuals returns
  *
@@ -62,6 +63,17 @@ int sr3_eval_psnr_ssim_f32(const float* sr_nchw, const float* hr_nchw, int n_ima
  * separately rounded multiply and add.  flip may be NULL (phase 'val'). */
 int sr3_images_u8_to_f32(const uint8_t* in_hwc, int n_images, int H, int W, int C, const uint8_t* flip, float lo, float hi,
                          float* out_nchw, void* stream);
+
+/* Data preparation (data/prepare_data.py:17-40 resize_and_convert / resize_multiple): PIL.Image.resize(size,
+ * resample) of n_images uint8 (H, W, C) images to (OH, OW, C) for resample = 3 (Image.BICUBIC, the default of
+ * prepare_data.py) or 2 (Image.BILINEAR, its `--resample bilinear`), bit-exact with Pillow's ImagingResample
+ * (double-precision filter weights -- bicubic a = -0.5 -- over a support scaled by max(in/out, 1), normalised, 22-bit fixed
+ * point, horizontal then vertical pass over a uint8 intermediate, each with round-to-nearest and clamp).  The
+ * smaller-edge / centre-crop logic of torchvision's resize + center_crop lives in the Python mirror
+ * (data/prepare_data.py of the package).  scratch: 256-byte aligned, sr3_resize_scratch_bytes(...) bytes. */
+size_t sr3_resize_scratch_bytes(int n_images, int H, int W, int C, int OH, int OW);
+int sr3_resize_u8(const uint8_t* in_hwc, int n_images, int H, int W, int C, int OH, int OW, int resample, void* scratch,
+                  size_t scratch_bytes, uint8_t* out_hwc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -143,3 +143,73 @@ def transform_augment(img_list, split='val', min_max=(0, 1), flip=False):
         imgs = list(st)
     span = min_max[1] - min_max[0]
     return [(i * np.float32(span) + np.float32(min_max[0])).astype(np.float32) for i in imgs]
+
+
+# ---- data/prepare_data.py:17-40 -> PIL.Image.resize: Pillow's ImagingResample for 8-bit images, restated ------------
+# (Pillow itself is installed in this image, so tests/test_oracle_io.py pins this restatement against the real
+# `Image.resize` for many size pairs; libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+# ImagingResampleHorizontal_8bpc / Vertical_8bpc.)
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def _bilinear(x):
+    x = abs(x)
+    return 1.0 - x if x < 1.0 else 0.0
+
+
+def resample_coeffs(in_size, out_size, cubic=True):
+    filt, fsupport = (_bicubic, 2.0) if cubic else (_bilinear, 1.0)
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = fsupport * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int64)
+    kk = np.zeros((out_size, ksize), dtype=np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [filt((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _resample_axis(img, out_size, axis, cubic):
+    img = np.moveaxis(np.asarray(img, dtype=np.int64), axis, 0)
+    bounds, kk = resample_coeffs(img.shape[0], out_size, cubic)
+    out = np.zeros((out_size,) + img.shape[1:], dtype=np.int64)
+    for xx in range(out_size):
+        lo, n = bounds[xx]
+        acc = np.full(img.shape[1:], 1 << (PRECISION_BITS - 1), dtype=np.int64)
+        for x in range(n):
+            acc += img[lo + x] * kk[xx, x]
+        out[xx] = np.clip(acc >> PRECISION_BITS, 0, 255)
+    return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+
+def pil_resize(img_u8_hwc, out_hw, cubic=True):
+    """Image.resize((OW, OH), BICUBIC | BILINEAR) of an (H, W, C) uint8 array: horizontal pass, then vertical."""
+    a = np.asarray(img_u8_hwc)
+    if a.shape[1] != out_hw[1]:
+        a = _resample_axis(a, out_hw[1], 1, cubic)
+    if a.shape[0] != out_hw[0]:
+        a = _resample_axis(a, out_hw[0], 0, cubic)
+    return a

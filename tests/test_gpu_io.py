@@ -165,3 +165,67 @@ def test_device_batches_feed_the_model(tmp_path):
     assert set(vb) == {'HR', 'SR', 'LR', 'Index'} and tuple(vb['LR'].shape) == (1, 3, 16, 16)
     img = np.asarray(Image.open(os.path.join(root, 'lr_16', '00000.png')).convert('RGB'))
     assert np.array_equal(vb['LR'][0].cpu().numpy(), O.transform_augment([img], 'val', (-1, 1))[0])
+
+
+def _tv_resize_center_crop(pil, size, resample):
+    """torchvision.transforms.functional.resize(img, int) + center_crop(img, int), restated with PIL calls only."""
+    w, h = pil.size
+    if not ((w <= h and w == size) or (h <= w and h == size)):
+        ow, oh = (size, int(size * h / w)) if w < h else (int(size * w / h), size)
+        pil = pil.resize((ow, oh), resample)
+    w, h = pil.size
+    top, left = int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+    return pil.crop((left, top, left + size, top + size))
+
+
+@pytest.mark.parametrize('cubic', [True, False], ids=['bicubic', 'bilinear'])
+def test_resize_batch_is_pillow_bit_exact(cubic):
+    import data.prepare_data as P
+    from PIL import Image
+    from test_oracle_io import RESIZE_CASES
+    rs = Image.BICUBIC if cubic else Image.BILINEAR
+    rng = np.random.RandomState(2)
+    for (h, w, oh, ow) in RESIZE_CASES + [(512, 512, 64, 64), (1024, 1024, 128, 128), (100, 160, 512, 300)]:
+        n = 3
+        a = rng.randint(0, 256, size=(n, h, w, 3)).astype(np.uint8)
+        a[0, : h // 2] = np.where(rng.rand(h // 2, w, 3) < 0.5, 0, 255)
+        got = P.resize_batch(torch.from_numpy(a), (oh, ow), rs).cpu().numpy()
+        for i in range(n):
+            ref = np.asarray(Image.fromarray(a[i]).resize((ow, oh), rs))
+            assert np.array_equal(got[i], ref), (h, w, oh, ow, i)
+    g1 = rng.randint(0, 256, size=(2, 40, 30, 1)).astype(np.uint8)
+    got = P.resize_batch(torch.from_numpy(g1).cuda(), (16, 16), rs).cpu().numpy()
+    assert np.array_equal(got[1, :, :, 0], np.asarray(Image.fromarray(g1[1, :, :, 0]).resize((16, 16), rs)))
+    with pytest.raises(NotImplementedError):
+        P.resize_batch(torch.from_numpy(g1), (8, 8), Image.NEAREST)
+
+
+def test_prepare_data_triplets_match_the_reference_pipeline(tmp_path):
+    """resize_multiple / prepare (data/prepare_data.py:17-40, 88-157): LR, HR, SR files byte-identical to what
+    torchvision resize + center_crop on Pillow produce."""
+    import data.prepare_data as P
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    src = tmp_path / 'src'
+    os.makedirs(src)
+    shapes = [(256, 256), (300, 200), (180, 260), (128, 128)]
+    for i, (h, w) in enumerate(shapes):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 127 + 90 * np.sin(yy / 9.0 + i)[:, :, None] * np.cos(xx / 13.0)[:, :, None] * np.ones((1, 1, 3))
+        Image.fromarray(np.clip(base + rng.randn(h, w, 3) * 20, 0, 255).astype(np.uint8)).save(str(src / ('%d.png' % i)))
+    out = str(tmp_path / 'out_16_128')
+    assert P.prepare(str(src), out, n_worker=3, sizes=(16, 128), resample=Image.BICUBIC) == 4
+    for i in range(4):
+        img = Image.open(str(src / ('%d.png' % i))).convert('RGB')
+        lr = _tv_resize_center_crop(img, 16, Image.BICUBIC)
+        hr = _tv_resize_center_crop(img, 128, Image.BICUBIC)
+        sr = _tv_resize_center_crop(lr, 128, Image.BICUBIC)
+        for sub, ref in (('lr_16', lr), ('hr_128', hr), ('sr_16_128', sr)):
+            got = np.asarray(Image.open(os.path.join(out, sub, '%05d.png' % i)))
+            assert got.shape == np.asarray(ref).shape and np.array_equal(got, np.asarray(ref)), (i, sub)
+    # the prepared directory feeds the drop-in dataset
+    import data as Data
+    ds = Data.create_dataset(dict(name='p', mode='LRHR', dataroot=out, datatype='img', l_resolution=16, r_resolution=128, data_len=-1), 'val')
+    assert len(ds) == 4 and tuple(ds[0]['SR'].shape) == (128, 128, 3)
+    lr_b, hr_b, sr_b = P.resize_multiple(Image.open(str(src / '0.png')).convert('RGB'), (16, 128), Image.BICUBIC, lmdb_save=True)
+    assert np.array_equal(np.asarray(Image.open(__import__('io').BytesIO(sr_b))), np.asarray(Image.open(os.path.join(out, 'sr_16_128', '00000.png'))))

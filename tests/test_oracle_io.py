@@ -120,3 +120,22 @@ def test_io_entry_points_fail_loudly_without_gpu():
         M.calculate_psnr(np.zeros((16, 16, 3), np.uint8), np.zeros((16, 16, 3), np.uint8))
     with pytest.raises(L.Sr3Error):
         U.transform_augment([np.zeros((4, 4, 3), np.uint8)])
+
+
+RESIZE_CASES = [(128, 128, 16, 16), (16, 16, 128, 128), (37, 53, 16, 23), (20, 31, 64, 40), (256, 256, 64, 64),
+                (64, 64, 512, 512), (33, 33, 33, 50), (50, 20, 20, 20), (12, 300, 12, 16), (5, 7, 1, 1), (1, 1, 9, 4)]
+
+
+@pytest.mark.parametrize('cubic', [True, False], ids=['bicubic', 'bilinear'])
+def test_pillow_resample_restatement_matches_pillow(cubic):
+    """data/prepare_data.py's arithmetic is PIL.Image.resize: pin the restatement against the installed Pillow."""
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    for (h, w, oh, ow) in RESIZE_CASES:
+        for ch in (3, 1):
+            a = rng.randint(0, 256, size=(h, w, ch)).astype(np.uint8)
+            a[: h // 2] = np.where(rng.rand(h // 2, w, ch) < 0.5, 0, 255)           # saturating edges: exercises the clamp
+            pil = Image.fromarray(a if ch == 3 else a[:, :, 0])
+            ref = np.asarray(pil.resize((ow, oh), Image.BICUBIC if cubic else Image.BILINEAR))
+            got = O.pil_resize(a, (oh, ow), cubic)
+            assert np.array_equal(got.reshape(ref.shape), ref), (h, w, oh, ow, ch)
