@@ -39,7 +39,8 @@ size_t wgrad_slab_bytes(const ConvParams& c, int* msplit_out);
 int conv_wgrad(const WgradParams& p, hipStream_t st);
 
 // Attention backward (attention_bwd.hip): qkv [B][N][3C], dout [B][N][C] -> dqkv [B][N][3C] (overwritten)
-int attention_backward(const float* qkv, const float* dout, int B, int N, int C, float* dqkv, hipStream_t st);
+// out_fwd (the forward attention output [B][N][C]) is only read by the key-blocked path (N too large for LDS strips)
+int attention_backward(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv, hipStream_t st);
 
 // Embedding / FiLM backward (small): see train_small.hip
 struct EmbedBwdParams {

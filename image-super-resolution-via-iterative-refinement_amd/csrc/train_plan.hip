@@ -126,7 +126,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       SR3_HIP(hipMemcpyAsync(grads + r.w, dwtmp, (size_t)P->out_ch * 9 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (r.kind == R_ATTN) {
       const Tensor& o = P->ttens[r.o];
-      rc = attention_backward(X.act(r.qkv), X.grad(r.o), B, o.H * o.W, o.C, X.grad(r.qkv), st);
+      rc = attention_backward(X.act(r.qkv), X.grad(r.o), X.act(r.o), B, o.H * o.W, o.C, X.grad(r.qkv), st);
       if (rc) return rc;
     } else if (r.kind == R_CONV_IN) {
       const Tensor& o = P->ttens[r.out];

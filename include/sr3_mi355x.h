@@ -207,6 +207,10 @@ int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* st
                            int groups, const float* gamma, const float* beta, float eps, float* ss, void* stream);
 /* SelfAttention core (unet.py:127-139): qkv NHWC [B][N][3C] -> out [B][N][C] */
 int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream);
+/* backward of the attention core (autograd of unet.py:127-139): dqkv [B][N][3C] from qkv, d(out) [B][N][C]; out_fwd
+ * (the forward output) may be NULL when N <= ~480 -- larger N use a key-blocked pass that reads it */
+int sr3_attention_bwd_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
+                          void* stream);
 /* noise-level / timestep embedding + MLP + all FiLM rows (unet.py:18-50,179-184): see sr3_common.h */
 int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep,
                        const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -199,6 +199,41 @@ def test_attention(B, N, C):
     G.assert_close(out.cpu(), ref, what='attention')
 
 
+@pytest.mark.parametrize('B,N,C', [(2, 64, 32), (1, 256, 512), (2, 100, 48), (1, 1024, 64), (1, 1024, 1024), (2, 600, 96), (1, 480, 64),
+                                   (1, 512, 128)])
+def test_attention_backward(B, N, C):
+    """dqkv of the attention core vs float64 autograd; N > ~480 takes the key-blocked path (needs the forward output)."""
+    lib = L.load()
+    d = G.dev()
+    qkv = _rand(B, N, 3 * C, seed=11) * (2.0 if C < 256 else 1.0)
+    dout = _rand(B, N, C, seed=12)
+    qd, gd = qkv.to(d), dout.to(d)
+    out = torch.empty(B, N, C, device=d)
+    L.check(lib.sr3_attention_f32(L.ptr(qd), B, N, C, L.ptr(out), G.stream()))
+    dq = torch.full((B, N, 3 * C), float('nan'), device=d)
+    L.check(lib.sr3_attention_bwd_f32(L.ptr(qd), L.ptr(gd), L.ptr(out), B, N, C, L.ptr(dq), G.stream()))
+    torch.cuda.synchronize()
+    x = qkv.double().requires_grad_(True)
+    q, k, v = x.split(C, dim=2)
+    o = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+    o.backward(dout.double())
+    ref = x.grad
+    got = dq.cpu().double()
+    for name, sl in (('dq', slice(0, C)), ('dk', slice(C, 2 * C)), ('dv', slice(2 * C, 3 * C))):
+        r, g_ = ref[:, :, sl], got[:, :, sl]
+        rel = (g_ - r).norm() / r.norm()
+        assert rel < 2e-5, (name, float(rel))
+        assert (g_ - r).abs().max() <= 1e-4 * max(1.0, float(r.abs().max())), name
+    if N <= 256:            # the single-strip path does not read the forward output
+        dq2 = torch.empty_like(dq)
+        L.check(lib.sr3_attention_bwd_f32(L.ptr(qd), L.ptr(gd), None, B, N, C, L.ptr(dq2), G.stream()))
+        torch.cuda.synchronize()
+        assert torch.allclose(dq2, dq, rtol=1e-4, atol=1e-5)
+    elif N >= 1024:
+        with pytest.raises(L.Sr3Error):
+            L.check(lib.sr3_attention_bwd_f32(L.ptr(qd), L.ptr(gd), None, B, N, C, L.ptr(dq), G.stream()))
+
+
 @pytest.mark.parametrize('variant', [0, 1])
 def test_film_embed(variant):
     lib = L.load()
