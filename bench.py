@@ -22,6 +22,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -259,6 +260,8 @@ def main():
                          '"f32 via 3xbf16 split MFMA"; the default is the exact-fp32 MFMA path)')
     ap.add_argument('--train-steps', type=int, default=10, help='0 disables the training leg')
     ap.add_argument('--train-batch', type=int, default=64, help='images per GPU (BASELINE config: 64)')
+    ap.add_argument('--extra-leg-timeout', type=int, default=420,
+                    help='seconds after which the roofline / split / train / cpu legs are abandoned and the line is printed')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -327,13 +330,51 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     images_per_s = world * B / (T * ms_per_step * 1e-3)
 
-    split = None
+    # ---- the headline record is complete here; everything below is an extra leg that must never cost the line ----
+    flops_step = netG.denoise_fn.plan.forward_flops(B)
+    rec = {
+        'metric': 'SR3 16->128 images/sec (2000-step sample)', 'value': images_per_s, 'unit': 'images/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 via 3xbf16 split MFMA' if a.split_bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': 'SR3 16->128 UNet (reference config/sr_sr3_16_128.json), batch %d per GPU, '
+                               '2000-step p_sample_loop via hipGraph replay; step = one reverse step of the batch; '
+                               'images/s = n_gpus*batch/(2000*t_step)' % B,
+                   'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': 128,
+                   'params': 97807491, 'parallelism': 'independent batches per rank (no collective)',
+                   'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
+        'step_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,
+        'step_frac_of_fp32_mfma_peak': flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+    }
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(False):
+            return
+        if rank == 0:
+            if note:
+                rec['note'] = note
+            print(json.dumps(rec), flush=True)
+
+    def watchdog():
+        # an extra leg hung (e.g. a collective on a sick node): the headline measurement is already done -- print it
+        emit('extra legs abandoned after %d s (watchdog); headline fields are complete' % a.extra_leg_timeout)
+        os._exit(0)
+    timer = threading.Timer(a.extra_leg_timeout, watchdog)
+    timer.daemon = True
+    timer.start()
+
+    if rank == 0 and not a.no_roofline:
+        level = torch.full((B,), 0.5, device=dev)
+        try:
+            rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+        except Exception as e:
+            rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and not a.no_split_leg and not a.split_bf16:
         try:
-            split = split_bf16_leg(netG, st['cond'], T, dev)
+            rec['split_bf16'] = split_bf16_leg(netG, st['cond'], T, dev)
         except Exception as e:
-            split = {'error': '%s: %s' % (type(e).__name__, e)}
-    train = None
+            rec['split_bf16'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if a.train_steps > 0:
         # free the sampling state first (graph, workspace) -- the training workspace is ~18 GB at batch 64
         st['graph'] = None
@@ -343,41 +384,20 @@ def main():
             train = train_leg(dist, world, rank, dev, a.train_batch, a.train_steps, 2)
         except Exception as e:                      # the headline line must survive a failing extra leg
             train = {'error': '%s: %s' % (type(e).__name__, e)}
-    if rank == 0:
-        flops_step = netG.denoise_fn.plan.forward_flops(B)
-        rec = {
-            'metric': 'SR3 16->128 images/sec (2000-step sample)', 'value': images_per_s, 'unit': 'images/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 via 3xbf16 split MFMA' if a.split_bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'SR3 16->128 UNet (reference config/sr_sr3_16_128.json), batch %d per GPU, '
-                                   '2000-step p_sample_loop via hipGraph replay; step = one reverse step of the batch; '
-                                   'images/s = n_gpus*batch/(2000*t_step)' % B,
-                       'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': 128,
-                       'params': 97807491, 'parallelism': 'independent batches per rank (no collective)',
-                       'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
-            'step_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,
-            'step_frac_of_fp32_mfma_peak': flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-        }
-        if not a.no_roofline:
-            level = torch.full((B,), 0.5, device=dev)
-            try:
-                rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
-            except Exception as e:
-                rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        if split is not None:
-            rec['split_bf16'] = split
-        if train is not None:
-            rec['train'] = train
-        if not a.no_cpu_baseline and world == 1:
-            try:
-                rec['cpu_baseline'] = cpu_baseline(B)
-            except Exception as e:
-                rec['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-        print(json.dumps(rec), flush=True)
+        rec['train'] = train
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        try:
+            rec['cpu_baseline'] = cpu_baseline(B)
+        except Exception as e:
+            rec['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    timer.cancel()
+    emit()
     if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == '__main__':

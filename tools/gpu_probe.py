@@ -292,8 +292,8 @@ def config_times(out_path):
         del arena, ws, x, out
 
 
-def train_time(B, out_path, iters=5):
-    """SR3 16->128 training step (forward + backward + Adam) timing at batch B."""
+def train_time(B, out_path, iters=5, config='sr3_16_128'):
+    """Training step (forward + backward + Adam) timing at batch B: SR3 16->128 (C3), DDPM-128 (C5) or SR3 64->512."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, ROOT)
     import importlib.util
@@ -304,10 +304,21 @@ def train_time(B, out_path, iters=5):
     opt = bench.sr3_16_128_opt()
     opt['phase'] = 'train'
     opt['model']['unet']['dropout'] = 0
+    S = 128
+    if config == 'ddpm_128':          # config/sample_ddpm_128.json
+        opt['model']['which_model_G'] = 'ddpm'
+        opt['model']['unet'].update(in_channel=3, channel_multiplier=[1, 1, 2, 2, 4, 4])
+        opt['model']['diffusion']['conditional'] = False
+        for ph in ('train', 'val'):
+            opt['model']['beta_schedule'][ph].update(linear_start=1e-4, linear_end=2e-2)
+    elif config == 'sr3_64_512':      # config/sr_sr3_64_512.json
+        S = 512
+        opt['model']['unet'].update(channel_multiplier=[1, 2, 4, 8, 16], attn_res=[], res_blocks=1, norm_groups=16)
+        opt['model']['diffusion']['image_size'] = 512
     torch.manual_seed(0)
     m = Model.create_model(opt)
     d = torch.device('cuda:0')
-    data = {'HR': torch.rand(B, 3, 128, 128) * 2 - 1, 'SR': torch.rand(B, 3, 128, 128) * 2 - 1}
+    data = {'HR': torch.rand(B, 3, S, S) * 2 - 1, 'SR': torch.rand(B, 3, S, S) * 2 - 1}
     m.feed_data(data)
     for _ in range(2):
         m.optimize_parameters()
@@ -318,7 +329,7 @@ def train_time(B, out_path, iters=5):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / iters
     fl = 3 * m.netG.denoise_fn.plan.forward_flops(B)
-    rec = dict(what='train_step', B=B, ms=dt * 1e3, img_per_s=B / dt, tflops_3x_fwd=fl / dt / 1e12, l_pix=m.get_current_log()['l_pix'],
+    rec = dict(what='train_step', config=config, B=B, ms=dt * 1e3, img_per_s=B / dt, tflops_3x_fwd=fl / dt / 1e12, l_pix=m.get_current_log()['l_pix'],
                ws_gb=m.netG.denoise_fn._train_ws.numel() / 1e9)
     with open(out_path, 'a') as f:
         f.write(json.dumps(rec) + '\n')
@@ -340,10 +351,11 @@ if __name__ == '__main__':
     ap.add_argument('--opcmp', action='store_true')
     ap.add_argument('--io', action='store_true')
     ap.add_argument('--train', default='')
+    ap.add_argument('--train-config', default='sr3_16_128')
     a = ap.parse_args()
     if a.train:
         for bb in [int(v) for v in a.train.split(',')]:
-            train_time(bb, os.path.join(OUT, 'probe_train.jsonl'))
+            train_time(bb, os.path.join(OUT, 'probe_train.jsonl'), config=a.train_config)
     if a.io:
         io_times(os.path.join(OUT, 'probe_io.jsonl'))
     if a.opcmp:
