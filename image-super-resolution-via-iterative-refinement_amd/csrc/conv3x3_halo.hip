@@ -74,6 +74,10 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   const int H = p.Ho, W = p.Wo;               // stride 1: output dims == virtual input dims
   const int tiles_n = (p.Cout + BN - 1) / BN;
   int bid = blockIdx.x;
+  // XCD-aware order: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so
+  // give every XCD one contiguous range of tiles -- the Cout siblings of a spatial tile and its neighbours then share
+  // their input halo through a single L2 instead of fetching it once per XCD.
+  if ((gridDim.x & 7) == 0 && !(p.dbg & 4)) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
   const int tile_n = bid % tiles_n;
   bid /= tiles_n;
   const int tw_i = bid % g.tiles_w;
