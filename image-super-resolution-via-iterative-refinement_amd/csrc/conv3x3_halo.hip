@@ -17,7 +17,12 @@
 // 32x32 MFMA tiles.  Fragment k-ordering as in conv_igemm.hip (one ds_read_b128 = 4 k-steps).
 // Epilogue: accumulators are transposed through wave-private LDS so that bias / FiLM / residual
 // loads and the NHWC stores are 16-byte wide; optional fused per-(image, channel) statistics of the
-// output for the next GroupNorm (double atomics).
+// output for the next GroupNorm: one partial {sum, sumsq} (double) per (image, tile, channel), written with
+// plain stores and summed in a fixed order by the fold kernel (no atomics, bitwise reproducible).
+//
+// Instantiations: 4 waves (128x128 or 256x64 tile, two workgroups per CU) or 8 waves (256x128, one per CU);
+// X2 = a fused second K-segment (the 1x1 res_conv); DROP = train-mode dropout in the staging step; MODE 1 =
+// opt-in split-bf16 MFMA (see below).  Workgroup order is XCD-aware.
 #include <stdlib.h>
 
 #include <type_traits>
