@@ -53,7 +53,7 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
 // split into three bf16 terms in the staging step and each product is evaluated as the six bf16 MFMA products
 // hh + hm + mh + mm + hl + lh (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the dropped terms are <= 2^-23 of
 // the product, i.e. fp32-class accuracy at 6/16 of the matrix-pipe time of the fp32 instruction.
-template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE>
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE, int NI>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 4 ? 2 : 1)
 void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;     // 4 waves (two workgroups per CU) or 8 (one)
@@ -61,7 +61,8 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   constexpr int LDK = 36, BK = 32;
   constexpr int LDB = 40;                     // MODE 1: bf16 row stride (32 + 8 pad), 80 bytes
   constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;   // weight stages: the 4-wave MODE 1 tile single-buffers to keep two workgroups per CU
-  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int WCOLS = 32 * NI;              // columns of a wave's tile: NI 32x32 MFMA tiles side by side (64 rows x WCOLS)
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * WCOLS;
   constexpr int BR = BN / RPP;                // weight loader rows per thread
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
   constexpr int HI = (HP_MAX * 8 + NT - 1) / NT; // halo float4 items per thread
@@ -246,13 +247,13 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     const int tx = m & (g.TW - 1);
     hbase[i] = nb * g.HPI + ty * TWp + tx;
   }
-  const int brow = wave_n * 64 + (lane & 31);
+  const int brow = wave_n * WCOLS + (lane & 31);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NI];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -262,14 +263,14 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {          // two K = 16 steps per 32-channel chunk
         const int off = ks * 16 + (lane >> 5) * 8;
-        bf16x8 a[2][3], b[2][3];
+        bf16x8 a[2][3], b[NI][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
             a[i][pl] = *reinterpret_cast<const bf16x8*>(&halo_b[(pl * HP_MAX + hbase[i] + shift) * LDB + off]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
             b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[(pl * BN + brow + 32 * j) * LDB + off]);
@@ -280,7 +281,7 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NI; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
       }
       return;
@@ -292,13 +293,13 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const f32x4*>(&halo[(hbase[i] + shift) * LDK + kk * 8 + kh]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bw[(brow + 32 * j) * LDK + kk * 8 + kh]);
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(&Bw[(brow + 32 * j) * LDK + kk * 8 + kh]);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
     }
   };
@@ -368,8 +369,9 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   const bool direct = p.ksplit == 1;
   const size_t Mtot = (size_t)p.B * H * W;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
-  const int c4 = lane & 15;                        // this lane's float4 column within the 64-wide wave tile
-  const int n = tile_n * BN + wave_n * 64 + c4 * 4;
+  constexpr int C4N = 8 * NI;                      // float4 columns of the wave tile; 64 / C4N rows per pass
+  const int c4 = lane % C4N;                       // this lane's float4 column within the wave tile
+  const int n = tile_n * BN + wave_n * WCOLS + c4 * 4;
   const bool nok = n < p.Cout;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -377,7 +379,7 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         tr[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + 32 * j + (lane & 31)] = acc[i][j][r];
@@ -391,8 +393,8 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     f32x4 film4 = {0.f, 0.f, 0.f, 0.f};
     if (direct && nok && p.film && b < p.B) film4 = *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int row = (lane >> 4) + 4 * e;
+    for (int e = 0; e < C4N / 2; ++e) {
+      const int row = lane / C4N + (64 / C4N) * e;
       const int m = mblk + row;
       const int ty = (m >> g.log_tw) & (g.TH - 1);
       const int tx = m & (g.TW - 1);
@@ -416,12 +418,12 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     if (direct && p.ostat) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        s1[k] += __shfl_xor(s1[k], 16); s1[k] += __shfl_xor(s1[k], 32);
-        s2[k] += __shfl_xor(s2[k], 16); s2[k] += __shfl_xor(s2[k], 32);
+#pragma unroll
+        for (int o = C4N; o < 64; o <<= 1) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
       }
-      if (lane < 16) {
+      if (lane < C4N) {
         // sred[row block][column of the tile][2]; row block = wave_m * 2 + i
-        double* o = sred + ((size_t)(wave_m * 2 + i) * BN + wave_n * 64 + c4 * 4) * 2;
+        double* o = sred + ((size_t)(wave_m * 2 + i) * BN + wave_n * WCOLS + c4 * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { o[2 * k] = s1[k]; o[2 * k + 1] = s2[k]; }
       }
@@ -456,9 +458,9 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
 namespace {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE>
+template <int WAVES_M, int WAVES_N, bool X2, bool DROP, int MODE, int NI>
 int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
-  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 64;
+  constexpr int BM = WAVES_M * 64, BN = WAVES_N * 32 * NI;
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;
@@ -466,7 +468,7 @@ int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int smem_epi = NW * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr_set = false;
-  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP, MODE>;
+  auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP, MODE, NI>;
   if (!attr_set) {
     SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -503,26 +505,31 @@ bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g) {
 int halo_stats_slices(const HaloGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 1; }
 
 namespace {
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int MODE, int NI = 2>
 int launch_halo_x(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   if (p.drop_thresh != 0) {       // train-mode block2 convs only
-    if constexpr (MODE == 1 || WM * WN != 4) {
+    if constexpr (MODE == 1 || !(WM == 2 && WN == 2)) {
       set_error("conv: this halo tile has no dropout instantiation");
       return SR3_E_UNSUPPORTED;
     } else {
-      return p.x2_w ? launch_halo<WM, WN, true, true, 0>(p, g, st) : launch_halo<WM, WN, false, true, 0>(p, g, st);
+      return p.x2_w ? launch_halo<WM, WN, true, true, 0, NI>(p, g, st) : launch_halo<WM, WN, false, true, 0, NI>(p, g, st);
     }
   }
-  return p.x2_w ? launch_halo<WM, WN, true, false, MODE>(p, g, st) : launch_halo<WM, WN, false, false, MODE>(p, g, st);
+  return p.x2_w ? launch_halo<WM, WN, true, false, MODE, NI>(p, g, st) : launch_halo<WM, WN, false, false, MODE, NI>(p, g, st);
 }
 }  // namespace
 
 int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st) {
   switch (cfg) {
     case 5: return launch_halo_x<2, 2, 0>(p, g, st);
-    case 6: return launch_halo_x<4, 1, 0>(p, g, st);
+    case 6:
+      // train-mode dropout: the 4-wave 64x64 form of this tile spills ~150 VGPRs with the mask hash in the staging
+      // step; the same 256x64 tile on 8 waves of 64x32 does not
+      if (p.drop_thresh != 0)
+        return p.x2_w ? launch_halo<4, 2, true, true, 0, 1>(p, g, st) : launch_halo<4, 2, false, true, 0, 1>(p, g, st);
+      return launch_halo_x<4, 1, 0>(p, g, st);
     case 7: return launch_halo_x<2, 2, 1>(p, g, st);    // opt-in 3 x bf16 split MFMA (inference only)
-    case 8: return launch_halo_x<4, 1, 1>(p, g, st);
+    case 8: return launch_halo_x<4, 2, 1, 1>(p, g, st);   // 256x64 on 8 waves of 64x32 (the 4-wave 64x64 form spills)
     case 9: return launch_halo_x<4, 2, 0>(p, g, st);    // 8 waves, one workgroup per CU
     case 10: return launch_halo_x<4, 2, 1>(p, g, st);
   }

@@ -369,7 +369,7 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     // step, 256 -> 14.96 ms; SR3_KSPLIT_TILES overrides)
     static const long split_below_env = getenv("SR3_KSPLIT_TILES") ? atol(getenv("SR3_KSPLIT_TILES")) : 384;
     // the 8-wave tiles run one workgroup per CU: one full round of 256 is the target there
-    const bool wide = tile_cfg >= 9;
+    const bool wide = halo_cfg_one_wg_per_cu(tile_cfg);
     const long split_below = wide ? 256 : split_below_env;
     if (tiles < split_below) {
       ks = (int)(((wide ? 256 : 512) + tiles - 1) / tiles);

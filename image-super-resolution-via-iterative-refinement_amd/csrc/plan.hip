@@ -383,19 +383,17 @@ struct Builder {
       o.tile_cfg = 5; o.ksplit = P->ksplit;
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
-    // the 256x64 dropout instantiation spills registers but still beats the half-empty 128x128 tile on the
-    // 64-channel layers (A/B on MI355X: 219.7 vs 222.2 ms per step); SR3_DROP_CFG5 forces the latter
+    // dropout convs on the 256x64 tile run its 8-wave form (conv3x3_halo_forward); SR3_DROP_CFG5 forces the
+    // half-empty 128x128 tile instead (A/B knob)
     static const bool use5 = getenv("SR3_DROP_CFG5") != nullptr;
     if (o.has_drop && o.tile_cfg == 6 && use5) {
       o.tile_cfg = 5; o.ksplit = P->ksplit;
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
     // opt-in: run the halo-tile convs on the 3 x bf16 split MFMA instantiations (inference plans only)
-    // (the 256x64 split instantiation spills and loses to its fp32 twin, so Cout <= 64 layers stay on tile 6)
-    // split_bf16 = 2 maps tile 6 -> 8 as well (tests / experiments)
     if (P->split_bf16 && !train && o.tile_cfg == 5) o.tile_cfg = 7;
     else if (P->split_bf16 && !train && o.tile_cfg == 9) o.tile_cfg = 10;
-    else if (P->split_bf16 >= 2 && !train && o.tile_cfg == 6) o.tile_cfg = 8;
+    else if (P->split_bf16 && !train && o.tile_cfg == 6) o.tile_cfg = 8;
     if (train) {
       Rec r;
       r.kind = R_CONV; r.x0 = x0; r.x1 = x1; r.out = out; r.r0 = r0; r.r1 = r1; r.q0 = q0; r.q1 = q1;

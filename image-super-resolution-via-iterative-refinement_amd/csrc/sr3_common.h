@@ -98,7 +98,9 @@ struct HaloGeom {
   int HPI, HP;             // halo pixels per image / per workgroup
 };
 // halo-tile configurations: 5 = 128(M) x 128(N), 6 = 256 x 64 (4 waves, two workgroups per CU); 9 = 256 x 128
-// (8 waves, one workgroup per CU); 7 / 8 / 10 = the split-bf16 instantiations of 5 / 6 / 9
+// (8 waves, one workgroup per CU); 7 / 8 / 10 = the split-bf16 instantiations of 5 / 6 / 9 (8 runs its 256 x 64
+// tile on 8 waves of 64 x 32)
+inline bool halo_cfg_one_wg_per_cu(int cfg) { return cfg >= 8; }
 inline int halo_cfg_bm(int cfg) { return (cfg == 5 || cfg == 7) ? 128 : 256; }
 inline int halo_cfg_bn(int cfg) { return (cfg == 6 || cfg == 8) ? 64 : 128; }
 inline bool halo_cfg_split(int cfg) { return cfg == 7 || cfg == 8 || cfg == 10; }

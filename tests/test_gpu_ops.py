@@ -111,6 +111,31 @@ def test_conv_fused_output_stats(ksplit, tile_cfg, case):
     assert torch.allclose(st[:, :, 1], s2, rtol=1e-9, atol=1e-9)
 
 
+@pytest.mark.parametrize('K', [(64, 0), (512, 0), (512, 512)], ids=['K576', 'K4608', 'K9216'])
+def test_split_bf16_error_is_fp32_class(K):
+    """The opt-in split-bf16 instantiations (tile 7 / 10) against a float64 reference: their error must be of the
+    same size as the exact-fp32 MFMA instantiations' (tile 5 / 9) on the same data -- i.e. no precision is given up."""
+    C0, C1 = K
+    B, H, Cout = 2, 32, 128
+    src0 = _rand(B, C0, H, H, seed=41) * 3.0
+    src1 = _rand(B, C1, H, H, seed=42) * 3.0 if C1 else None
+    w = _rand(Cout, C0 + C1, 3, 3, seed=43) * (1.0 / math.sqrt(9 * (C0 + C1)))
+    ss = torch.stack([1.0 + 0.3 * _rand(B, C0 + C1, seed=44), 0.2 * _rand(B, C0 + C1, seed=45)], 2)
+    kw = dict(bias=_rand(Cout, seed=46), ss=ss, act=2)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    errs = {}
+    for cfg in (5, 7, 9, 10):
+        got, _ = G.conv_call(src0, src1, w, tile_cfg=cfg, ksplit=1, **kw)
+        d = (got.double() - ref)
+        errs[cfg] = (d.abs().max().item(), d.pow(2).mean().sqrt().item())
+    scale = ref.abs().max().item()
+    print('K=%d |ref|max %.2f  max/rms err: fp32 128x128 %.2e/%.2e  split %.2e/%.2e | fp32 256x128 %.2e/%.2e  split %.2e/%.2e'
+          % (9 * (C0 + C1), scale, *errs[5], *errs[7], *errs[9], *errs[10]))
+    for exact, split in ((5, 7), (9, 10)):
+        assert errs[split][0] <= 2.0 * errs[exact][0] + 1e-7 * scale, (errs[exact], errs[split])
+        assert errs[split][1] <= 2.0 * errs[exact][1] + 1e-8 * scale, (errs[exact], errs[split])
+
+
 @pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (5, 1), (6, 1), (5, 2), (6, 3), (7, 1), (8, 1), (9, 1), (10, 1), (9, 2)])
 @pytest.mark.parametrize('shape', [(2, 64, 0, 16, 16, 128, 96, 32), (3, 32, 0, 8, 8, 64, 24, 8), (1, 128, 0, 32, 32, 64, 192, 0)],
                          ids=['16x16', '8x8_oddB', '32x32'])
