@@ -59,7 +59,11 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   constexpr int NW = WAVES_M * WAVES_N, NT = NW * 64;     // 4 waves (two workgroups per CU) or 8 (one)
   constexpr int RPP = NT / 8;                 // tile rows one loader pass covers (8 threads x float4 per row)
   constexpr int LDK = 36, BK = 32;
-  constexpr int LDB = 40;                     // MODE 1: bf16 row stride (32 + 8 pad), 80 bytes
+  constexpr int LDB = 32;                     // MODE 1: bf16 row stride, 64 bytes, no padding: the four 16-byte segments of a
+                                              // row are XOR-swizzled with (row >> 2) & 3, which makes both the 8-byte staging
+                                              // writes (4 rows x 64 B per 32 lanes) and the 16-byte fragment reads (16
+                                              // consecutive rows x 16 B) bank-conflict free
+  auto swz = [](int row, int seg) { return row * LDB + (((seg ^ (row >> 2)) & 3) << 3); };   // bf16 index of a segment
   constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;   // weight stages: the 4-wave MODE 1 tile single-buffers to keep two workgroups per CU
   constexpr int WCOLS = 32 * NI;              // columns of a wave's tile: NI 32x32 MFMA tiles side by side (64 rows x WCOLS)
   constexpr int BM = WAVES_M * 64, BN = WAVES_N * WCOLS;
@@ -190,9 +194,10 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
         } else {
           bf16x4 h, m, l;
           split3(v, h, m, l);
-          *reinterpret_cast<bf16x4*>(&halo_b[(0 * HP_MAX + hp) * LDB + kq * 4]) = h;
-          *reinterpret_cast<bf16x4*>(&halo_b[(1 * HP_MAX + hp) * LDB + kq * 4]) = m;
-          *reinterpret_cast<bf16x4*>(&halo_b[(2 * HP_MAX + hp) * LDB + kq * 4]) = l;
+          const int o = swz(hp, kq >> 1) + (kq & 1) * 4;
+          *reinterpret_cast<bf16x4*>(&halo_b[0 * HP_MAX * LDB + o]) = h;
+          *reinterpret_cast<bf16x4*>(&halo_b[1 * HP_MAX * LDB + o]) = m;
+          *reinterpret_cast<bf16x4*>(&halo_b[2 * HP_MAX * LDB + o]) = l;
         }
       }
     }
@@ -227,7 +232,7 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
       for (int j = 0; j < BR; ++j) {
         bf16x4 h, m, l;
         split3(wok[j] ? rw[j] : zero, h, m, l);
-        const int o = (lrow + RPP * j) * LDB + kq * 4;
+        const int o = swz(lrow + RPP * j, kq >> 1) + (kq & 1) * 4;
         *reinterpret_cast<bf16x4*>(&Bb[0 * BN * LDB + o]) = h;
         *reinterpret_cast<bf16x4*>(&Bb[1 * BN * LDB + o]) = m;
         *reinterpret_cast<bf16x4*>(&Bb[2 * BN * LDB + o]) = l;
@@ -262,18 +267,20 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
       const __bf16* Bb = wst_b + stage * 3 * BN * LDB;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {          // two K = 16 steps per 32-channel chunk
-        const int off = ks * 16 + (lane >> 5) * 8;
+        const int seg = ks * 2 + (lane >> 5);       // 16-byte segment (8 channels) of the 32-channel row
         bf16x8 a[2][3], b[NI][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          const int o = swz(hbase[i] + shift, seg);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            a[i][pl] = *reinterpret_cast<const bf16x8*>(&halo_b[(pl * HP_MAX + hbase[i] + shift) * LDB + off]);
+          for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(&halo_b[pl * HP_MAX * LDB + o]);
+        }
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j) {
+          const int o = swz(brow + 32 * j, seg);
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[(pl * BN + brow + 32 * j) * LDB + off]);
+          for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * BN * LDB + o]);
+        }
         // product-major order: four independent accumulators between dependent MFMAs; smallest terms first
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -464,7 +471,7 @@ int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int HP_MAX = (BM == 128) ? 200 : 324;
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int WST = (MODE == 1 && NW == 4) ? 1 : 2;
-  constexpr int smem_main = MODE == 0 ? (HP_MAX * 36 + 2 * BN * 36) * 4 : (3 * HP_MAX * 40 + WST * 3 * BN * 40) * 2;
+  constexpr int smem_main = MODE == 0 ? (HP_MAX * 36 + 2 * BN * 36) * 4 : (3 * HP_MAX * 32 + WST * 3 * BN * 32) * 2;
   constexpr int smem_epi = NW * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
   static bool attr_set = false;

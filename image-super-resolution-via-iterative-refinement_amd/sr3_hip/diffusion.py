@@ -170,7 +170,7 @@ class EngineDiffusion(nn.Module):
     # ---- the reverse loop ------------------------------------------------------------------------
     def _loop_state(self, shape, cond_shape, dev):
         key = (tuple(shape), None if cond_shape is None else tuple(cond_shape), str(dev), self.num_timesteps,
-               self.denoise_fn.arena.data_ptr(), self.denoise_fn.plan.__dict__.get('options', {}).get('split_bf16', 0))
+               self.denoise_fn.arena.data_ptr(), self.denoise_fn.plan.options.get('split_bf16', 0))
         st = self._loop_cache.get(key)
         if st is None:
             st = dict(img=torch.empty(shape, device=dev), z=torch.empty(shape, device=dev),

@@ -50,6 +50,7 @@ class Plan(object):
         h = C.c_void_p()
         L.check(self.lib.sr3_plan_create(C.byref(self.desc), C.byref(h)))
         self.handle = h
+        self.options = {}          # plan options set through set_option (key -> value)
         self.param_floats = int(self.lib.sr3_plan_param_floats(h))
         self.table = []
         pi = L.ParamInfo()
@@ -70,7 +71,7 @@ class Plan(object):
         rc = self.lib.sr3_plan_set_option(self.handle, key.encode(), int(value))
         if rc < 0:
             L.check(rc)
-        self.__dict__.setdefault('options', {})[key] = int(value)
+        self.options[key] = int(value)
         return rc
 
     def workspace_bytes(self, batch):
