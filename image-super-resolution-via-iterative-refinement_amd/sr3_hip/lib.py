@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsr3_mi355x.so')
+# SR3_LIBRARY: load another build of the same ABI (in-run A/B of kernel changes); default: the in-tree library
+LIB_PATH = os.environ.get('SR3_LIBRARY') or os.path.join(_HERE, 'libsr3_mi355x.so')
 
 
 class Sr3Error(RuntimeError):
