@@ -133,12 +133,14 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             a[0] += ms[i]
             a[1] += fl[i]
             a[2] += 1
-    # template arguments: <WAVES_M, WAVES_N, fused 1x1 segment, dropout, 0 = fp32 MFMA | 1 = 3 x bf16 split MFMA>
-    names = {55: 'k_conv3x3_halo<2,2,false,false,0>', 56: 'k_conv3x3_halo<4,1,false,false,0>',
-             57: 'k_conv3x3_halo<2,2,true,false,0>', 58: 'k_conv3x3_halo<4,1,true,false,0>',
-             255: 'k_conv3x3_halo<4,2,false,false,0>', 257: 'k_conv3x3_halo<4,2,true,false,0>',
-             155: 'k_conv3x3_halo<2,2,false,false,1>', 157: 'k_conv3x3_halo<2,2,true,false,1>',
-             355: 'k_conv3x3_halo<4,2,false,false,1>', 357: 'k_conv3x3_halo<4,2,true,false,1>'}
+    # template arguments: <WAVES_M, WAVES_N, fused 1x1 segment, dropout, 0 = fp32 MFMA | 1 = 3 x bf16 split MFMA,
+    #                      32x32 MFMA tiles across a wave's tile>
+    names = {55: 'k_conv3x3_halo<2,2,false,false,0,2>', 56: 'k_conv3x3_halo<4,1,false,false,0,2>',
+             57: 'k_conv3x3_halo<2,2,true,false,0,2>', 58: 'k_conv3x3_halo<4,1,true,false,0,2>',
+             255: 'k_conv3x3_halo<4,2,false,false,0,2>', 257: 'k_conv3x3_halo<4,2,true,false,0,2>',
+             155: 'k_conv3x3_halo<2,2,false,false,1,2>', 157: 'k_conv3x3_halo<2,2,true,false,1,2>',
+             156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
+             355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -154,7 +156,7 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
             traffic = json.load(f)['sr3::' + names[dom].replace(',', ', ')]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         pass
-    is_split = names[dom].endswith(',1>')
+    is_split = names[dom].split(',')[4] == '1'
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
     return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
