@@ -845,6 +845,29 @@ int sr3_plan_num_ops(sr3_plan* plan, int batch) {
   if (build_forward(plan, batch, cond)) return -1;
   return (int)plan->ops.size();
 }
+int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
+  if (!plan || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
+  const int rc = build_forward(plan, batch, cond);
+  if (rc) return rc;
+  if (index < 0 || index >= (int)plan->ops.size()) { set_error("op index out of range"); return SR3_E_BADARG; }
+  const Op& o = plan->ops[index];
+  memset(out, 0, sizeof(*out));
+  out->kind = (int)o.kind * 10;
+  if (o.kind == OP_CONV) {
+    const ConvParams& c = o.cp;
+    out->tile_cfg = o.tile_cfg; out->ksplit = o.ksplit;
+    out->ksize = c.ksize; out->stride = c.stride; out->upsample = c.ups;
+    out->cin = c.C0 + c.C1; out->cout = c.Cout; out->h_out = c.Ho; out->w_out = c.Wo;
+    out->fused_res_conv_cin = o.has_x2 ? c.x2_C0 + c.x2_C1 : 0;
+    out->fused_output_stats = o.has_ostat ? 1 : 0;
+    out->flops = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)out->cin * c.ksize * c.ksize + out->fused_res_conv_cin);
+  } else if (o.kind == OP_ATTN) {
+    out->h_out = o.i0; out->cin = out->cout = o.i1;          // tokens, channels
+    out->flops = 4.0 * batch * (double)o.i0 * (double)o.i0 * o.i1;
+  }
+  return SR3_OK;
+}
 double sr3_plan_forward_flops(sr3_plan* plan, int batch) {
   if (!plan) return 0;
   const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;

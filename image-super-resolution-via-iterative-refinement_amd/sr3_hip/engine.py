@@ -86,6 +86,15 @@ class Plan(object):
     def num_ops(self, batch):
         return int(self.lib.sr3_plan_num_ops(self.handle, int(batch)))
 
+    def op_list(self, batch):
+        """The ordered launch list of one forward at this batch size (host-only inspection)."""
+        info = L.OpInfo()
+        out = []
+        for i in range(self.num_ops(batch)):
+            L.check(self.lib.sr3_plan_op_info(self.handle, int(batch), i, C.byref(info)))
+            out.append({k: getattr(info, k) for k, _ in L.OpInfo._fields_})
+        return out
+
     def taps(self):
         out = []
         name = C.create_string_buffer(64)

@@ -27,6 +27,12 @@ class ParamInfo(C.Structure):
                 ('offset', C.c_size_t), ('numel', C.c_size_t)]
 
 
+class OpInfo(C.Structure):
+    _fields_ = [('kind', C.c_int), ('tile_cfg', C.c_int), ('ksplit', C.c_int), ('ksize', C.c_int), ('stride', C.c_int),
+                ('upsample', C.c_int), ('cin', C.c_int), ('cout', C.c_int), ('h_out', C.c_int), ('w_out', C.c_int),
+                ('fused_res_conv_cin', C.c_int), ('fused_output_stats', C.c_int), ('flops', C.c_double)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _Z = C.c_size_t
@@ -52,6 +58,7 @@ SIGNATURES = {
     'sr3_plan_num_params': (_I, [_P]),
     'sr3_plan_param_info': (_I, [_P, _I, C.POINTER(ParamInfo)]),
     'sr3_plan_param_floats': (_Z, [_P]),
+    'sr3_plan_op_info': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(OpInfo)]),
     'sr3_plan_num_ops': (_I, [_P, _I]),
     'sr3_plan_forward_flops': (C.c_double, [_P, _I]),
     'sr3_plan_set_option': (_I, [_P, C.c_char_p, _I]),

@@ -75,6 +75,19 @@ int sr3_plan_param_info(const sr3_plan* plan, int index, sr3_param_info* out);
 size_t sr3_plan_param_floats(const sr3_plan* plan);
 /* ordered list of kernels one forward launches, for inspection / DESIGN.md: returns count */
 int sr3_plan_num_ops(sr3_plan* plan, int batch);
+/* one entry of that list: kind as in sr3_unet_forward_profile's op_kind / 10 * 10 (10 embed, 20 input conv, 30
+ * statistics, 40 GroupNorm fold, 50 convolution, 60 attention, 70 output block); for convolutions the tile
+ * configuration the plan picked (1-4 im2col kernel, 5-10 halo-tile kernel, see sr3_conv_f32), the split-K factor, the
+ * geometry and what is fused into the launch.  Host-only (no device work): lets tools and tests inspect the plan. */
+typedef struct sr3_op_info {
+  int kind, tile_cfg, ksplit;
+  int ksize, stride, upsample;
+  int cin, cout, h_out, w_out;          /* attention: cin = cout = channels, h_out = tokens */
+  int fused_res_conv_cin;               /* > 0: the 1x1 res_conv of that many input channels runs inside this launch */
+  int fused_output_stats;               /* 1: the launch also writes the next GroupNorm's partial statistics */
+  double flops;
+} sr3_op_info;
+int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16"};

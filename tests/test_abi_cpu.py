@@ -151,3 +151,50 @@ def test_optimizer_state_is_torch_adam_format():
     for e in un.plan.table:
         assert torch.equal(un.plan.view(optG2.exp_avg, e), un.plan.view(optG.exp_avg, e)), e['name']
         assert torch.equal(un.plan.view(optG2.exp_avg_sq, e), un.plan.view(optG.exp_avg_sq, e))
+
+
+def test_plan_launch_list_no_gpu():
+    """sr3_plan_op_info (host-only): the compiled launch list of the BASELINE config -- which kernel / tile each layer
+    gets, what is fused, and that the opt-in split option only re-targets halo-tile convolutions."""
+    from sr3_hip import engine as E
+    p = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    ops = p.op_list(16)
+    assert len(ops) == p.num_ops(16) == 151
+    convs = [o for o in ops if o['kind'] == 50]
+    assert sum(1 for o in ops if o['kind'] == 60) == 6 and sum(1 for o in ops if o['kind'] == 40) == 61
+    # every 3x3 stride-1 conv runs on the halo-tile kernel; 1x1 and stride-2 convs on the im2col kernel
+    for o in convs:
+        halo = o['tile_cfg'] >= 5
+        assert halo == (o['ksize'] == 3 and o['stride'] == 1), o
+        if o['fused_res_conv_cin']:
+            assert halo and not o['upsample']
+    # 18 ResnetBlocks change their channel count: their 1x1 res_conv rides inside block2's launch
+    assert sum(1 for o in convs if o['fused_res_conv_cin']) == 18
+    assert sum(1 for o in convs if o['ksize'] == 1) == 12              # qkv + out of the 6 attention blocks only
+    # Cout <= 64 layers: 256x64 tile; Cout > 64 layers whose 256x128 tiling still gives one workgroup per CU (256): the
+    # 8-wave tile; the remaining small-M layers: 128x128 + split-K
+    for o in convs:
+        if o['tile_cfg'] >= 5:
+            wg9 = 16 * (o['h_out'] // 16) * (o['w_out'] // 16) * -(-o['cout'] // 128) if o['h_out'] >= 16 else 0
+            if o['cout'] <= 64:
+                assert o['tile_cfg'] == 6
+            elif wg9 >= 256:
+                assert o['tile_cfg'] == 9 and o['ksplit'] == 1, o
+            else:
+                assert o['tile_cfg'] == 5 and o['ksplit'] > 1, o
+    total = sum(o['flops'] for o in ops) / 16 / 1e9
+    assert abs(total - 92.18) < 0.05 and abs(p.forward_flops(16) / 16 / 1e9 - 92.35) < 0.05
+    # opt-in split mode: same list, only the halo tiles change (5 -> 7 or 10, 6 -> 8, 9 -> 10)
+    p.set_option('split_bf16', 1)
+    ops2 = p.op_list(16)
+    assert len(ops2) == len(ops)
+    for a, b in zip(ops, ops2):
+        assert a['kind'] == b['kind'] and a['flops'] == b['flops']
+        if a['kind'] == 50 and a['tile_cfg'] >= 5:
+            assert b['tile_cfg'] in {5: (7, 10), 6: (8,), 9: (10,)}[a['tile_cfg']], (a, b)
+        else:
+            assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
+    p.set_option('split_bf16', 0)
+    assert p.op_list(16) == ops
+    # batch 1: everything is small-M
+    assert all(o['tile_cfg'] != 9 or o['h_out'] >= 128 for o in p.op_list(1) if o['kind'] == 50)
