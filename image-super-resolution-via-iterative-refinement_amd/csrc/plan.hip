@@ -883,6 +883,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "keep_all")) slot = &plan->keep_all;
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
+  else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
   *slot = value;

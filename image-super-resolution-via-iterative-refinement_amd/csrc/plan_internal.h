@@ -100,6 +100,7 @@ struct sr3_plan {
   int fin_cin = 0, out_ch = 0;
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
+  int loss_l2 = 0;           // training loss: 0 = L1 (sum), 1 = L2 (sum)  (set_loss, diffusion.py:84-90)
   // compiled forward
   int built_batch = -1;
   int built_cond = -1;

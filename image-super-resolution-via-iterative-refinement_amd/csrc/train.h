@@ -19,7 +19,7 @@ int zero_insert(const float* g, int B, int Ho, int Wo, int C, float* z, hipStrea
 int w_flip_transpose(const float* w, int Cout, int taps, int Cin, int CoutP, float* wt, hipStream_t st);
 int colsums(const float* g, int B, int HW, int C, double* part, float* dbias, float* dfilm, int film_stride,
             hipStream_t st);
-int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, float scale, float* g_nhwc,
+int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, float scale, bool l2, float* g_nhwc,
                  double* loss_part, float* loss_out, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
               hipStream_t st);

@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256) void k_w_flip_transpose(const float* __restric
   }
 }
 
-// T11: L1 loss (nn.L1Loss(reduction='sum'), diffusion.py:84-90,245) and its gradient w.r.t. eps_hat:
-// loss_part[block] = sum |z - e| ; g = -sign(z - e) * scale, written NHWC with the channel dim padded to CP.
+// T11: the pixel loss of set_loss (diffusion.py:84-90,245) and its gradient w.r.t. eps_hat, written NHWC with the
+// channel dim padded to CP.  L1 (nn.L1Loss(reduction='sum'), what define_G configures): loss_part[block] = sum |z - e|,
+// g = -sign(z - e) * scale.  L2 (nn.MSELoss(reduction='sum'), loss_type 'l2'): sum (z - e)^2, g = -2 (z - e) * scale.
+template <bool L2>
 __global__ __launch_bounds__(256) void k_l1_loss_grad(const float* __restrict__ z, const float* __restrict__ e, int B,
                                                        int Cc, int HW, int CP, float scale, float* __restrict__ g_nhwc,
                                                        double* __restrict__ loss_part) {
@@ -246,8 +248,13 @@ __global__ __launch_bounds__(256) void k_l1_loss_grad(const float* __restrict__ 
       if (c < Cc) {
         const size_t idx = (b * Cc + c) * HW + p;
         const float d = z[idx] - e[idx];
-        s += (double)fabsf(d);
-        gv = d > 0.f ? -scale : (d < 0.f ? scale : 0.f);
+        if (L2) {
+          s += (double)d * (double)d;
+          gv = -2.f * d * scale;
+        } else {
+          s += (double)fabsf(d);
+          gv = d > 0.f ? -scale : (d < 0.f ? scale : 0.f);
+        }
       }
       g_nhwc[i * CP + c] = gv;
     }
@@ -427,10 +434,11 @@ int colsums(const float* g, int B, int HW, int C, double* part, float* dbias, fl
   }
   return SR3_OK;
 }
-int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, float scale, float* g_nhwc,
+int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, float scale, bool l2, float* g_nhwc,
                  double* loss_part, float* loss_out, hipStream_t st) {
   const int blocks = 256;
-  hipLaunchKernelGGL(k_l1_loss_grad, dim3(blocks), dim3(256), 0, st, z, e, B, Cc, HW, CP, scale, g_nhwc, loss_part);
+  if (l2) hipLaunchKernelGGL(k_l1_loss_grad<true>, dim3(blocks), dim3(256), 0, st, z, e, B, Cc, HW, CP, scale, g_nhwc, loss_part);
+  else hipLaunchKernelGGL(k_l1_loss_grad<false>, dim3(blocks), dim3(256), 0, st, z, e, B, Cc, HW, CP, scale, g_nhwc, loss_part);
   SR3_LAUNCH_CHECK("k_l1_loss_grad");
   hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(64), 0, st, loss_part, blocks, loss_out);
   SR3_LAUNCH_CHECK("k_sum_parts");

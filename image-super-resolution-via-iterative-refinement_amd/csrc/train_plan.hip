@@ -82,7 +82,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   // ---- loss and its gradient (NHWC, channel dim padded to 4) ----
   float* geps = X.at<float>(P->t_geps_off);
   double* lparts = X.at<double>(P->t_dwtmp_off);
-  rc = l1_loss_grad(z, eps, B, P->out_ch, S * S, 4, grad_scale, geps, lparts, loss_out, st);
+  rc = l1_loss_grad(z, eps, B, P->out_ch, S * S, 4, grad_scale, P->loss_l2 != 0, geps, lparts, loss_out, st);
   if (rc) return rc;
   // ---- zero the activation-gradient mirror and the FiLM gradient table ----
   SR3_HIP(hipMemsetAsync(ws + P->t_act_bytes, 0, P->t_act_bytes, st));

@@ -69,6 +69,7 @@ class EngineDiffusion(nn.Module):
     def set_loss(self, device):
         if self.loss_type not in ('l1', 'l2'):
             raise NotImplementedError()
+        self.denoise_fn.plan.set_option('loss_l2', 1 if self.loss_type == 'l2' else 0)
         self.loss_device = device
 
     def set_new_noise_schedule(self, schedule_opt, device):

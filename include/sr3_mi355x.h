@@ -90,8 +90,10 @@ typedef struct sr3_op_info {
 int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
-/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16"};
+/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "loss_l2"};
  * returns previous value.
+ * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
+ *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
  * split_bf16 (default 0, experimental): run the halo-tile 3x3 convolutions of the inference plan on
  *   v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (x = h + m + l) and the six
  *   products hh, hm, mh, mm, hl, lh accumulated in fp32 -- fp32-class accuracy (dropped terms <= 2^-23 of a

@@ -330,24 +330,26 @@ def q_sample_sr3(x0, gamma, z):
     return gamma * x0 + (1 - gamma ** 2).sqrt() * z
 
 
-def p_losses_sr3(sd, desc, hr, sr, gamma, z, conditional=True, dropout=None):
+def p_losses_sr3(sd, desc, hr, sr, gamma, z, conditional=True, dropout=None, loss_type='l1'):
     """sr3 diffusion.py:221-246 with injected (gamma (B,), z); L1 sum (set_loss :84-90)."""
     b = hr.shape[0]
     g = gamma.view(b, -1)
     x_noisy = q_sample_sr3(hr, g.view(-1, 1, 1, 1), z)
     inp = torch.cat([sr, x_noisy], dim=1) if conditional else x_noisy
     eps = unet_forward(sd, desc, inp, g, dropout=dropout)
-    return (z - eps).abs().sum()
+    # set_loss (diffusion.py:84-90): nn.L1Loss(reduction='sum') | nn.MSELoss(reduction='sum')
+    return (z - eps).abs().sum() if loss_type == 'l1' else ((z - eps) ** 2).sum()
 
 
-def p_losses_ddpm(sd, desc, tab, hr, sr, t, z, conditional=False):
+def p_losses_ddpm(sd, desc, tab, hr, sr, t, z, conditional=False, loss_type='l1'):
     """ddpm diffusion.py:259-294 with injected (t (B,) int64, z)."""
     a = torch.from_numpy(tab['sqrt_alphas_cumprod'])[t].view(-1, 1, 1, 1)
     s = torch.from_numpy(tab['sqrt_one_minus_alphas_cumprod'])[t].view(-1, 1, 1, 1)
     x_noisy = a * hr + s * z
     inp = torch.cat([sr, x_noisy], dim=1) if conditional else x_noisy
     eps = unet_forward(sd, desc, inp, t)
-    return (z - eps).abs().sum()
+    # set_loss (diffusion.py:84-90): nn.L1Loss(reduction='sum') | nn.MSELoss(reduction='sum')
+    return (z - eps).abs().sum() if loss_type == 'l1' else ((z - eps) ** 2).sum()
 
 
 def desc_from_opt(opt):

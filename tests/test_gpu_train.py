@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import DESCS, CONDITIONAL, load_golden, opt_for      # noqa: E402
+from helpers import DESCS, SCHEDS, CONDITIONAL, load_golden, opt_for      # noqa: E402
 import gpu_util as G                                             # noqa: E402
 
 
@@ -114,6 +114,45 @@ def test_dropout_training_step_matches_oracle_autograd():
     assert not bad, sorted(bad, reverse=True)[:8]
     # eval mode ignores dropout: sampling path unchanged
     m.netG.eval()
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_l2_loss_training_step_matches_oracle_autograd(name):
+    """GaussianDiffusion(loss_type='l2') -> nn.MSELoss(reduction='sum') (set_loss, diffusion.py:84-90): loss and every
+    gradient against the oracle's autograd.  (define_G hard-codes 'l1', so the reference's callers never take this path.)"""
+    from oracle import sr3_oracle as O
+    import model as Model
+    m = Model.create_model(opt_for(name, phase='train', gpu=True))
+    g, sd = load_golden(name)
+    m.netG.load_state_dict(sd, strict=True)
+    m.netG.loss_type = 'l2'
+    m.netG.set_loss(G.dev())
+    d = G.dev()
+    hr, sr = torch.from_numpy(g['loop/hr']), torch.from_numpy(g['loop/sr'])
+    z = torch.from_numpy(g['train/z'])
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
+    if name == 'sr3_tiny':
+        gamma = torch.from_numpy(g['train/gamma'])
+        loss = m.netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), gamma=gamma)
+        ref_loss = O.p_losses_sr3(sdr, DESCS[name], hr, sr, gamma, z, conditional=True, loss_type='l2')
+    else:
+        t = torch.from_numpy(g['train/t'])
+        loss = m.netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), t=t)
+        ref_loss = O.p_losses_ddpm(sdr, DESCS[name], O.schedule_tables(SCHEDS[name]), hr, sr, t, z, conditional=False, loss_type='l2')
+    torch.cuda.synchronize()
+    (ref_loss / hr.numel()).backward()
+    assert abs(float(loss) - float(ref_loss.detach())) <= 1e-5 * abs(float(ref_loss.detach()))
+    assert abs(float(loss) - float(g['train/loss_sum'])) > 1e-3 * float(g['train/loss_sum'])      # not the L1 value
+    bad = []
+    for key, grad in m.netG.denoise_fn.named_gradients():
+        ref = sdr['denoise_fn.' + key].grad
+        num, den = (grad.cpu() - ref).norm().item(), max(ref.norm().item(), 1e-7)
+        if num / den > 1e-4 and den > 1e-6:
+            bad.append((num / den, key))
+    assert not bad, sorted(bad, reverse=True)[:8]
+    m.netG.loss_type = 'l1'
+    m.netG.set_loss(d)
+    assert m.netG.denoise_fn.plan.options['loss_l2'] == 0
 
 
 def test_dropout_mask_statistics():
