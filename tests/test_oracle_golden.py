@@ -89,3 +89,47 @@ def test_topology_matches_reference_counts():
     assert sum(l['kind'] == 'res' and l['attn'] for l in layers) == 6
     assert sum(l['kind'] == 'down' for l in layers) == 4 and sum(l['kind'] == 'up' for l in layers) == 4
     assert [l['cin'] for l in topo['ups'] if l['kind'] == 'res'][:4] == [1024, 1024, 1024, 1024]
+
+
+SCHED_NAMES = ['quad', 'linear', 'warmup10', 'warmup50', 'const', 'jsd', 'cosine']
+
+
+@pytest.mark.parametrize('sched', SCHED_NAMES)
+def test_every_beta_schedule_matches_reference(sched):
+    """make_beta_schedule for all seven names (reference diffusion.py:12-49; tests/golden/schedules.npz comes from the
+    reference itself, oracle/make_golden_sched.py): the oracle's and the engine's host code, float64, bit for bit."""
+    import os
+    from helpers import ROOT
+    from sr3_hip import diffusion as D
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'schedules.npz'))
+    for n in (20, 2000):
+        for flavour, (ls, le) in (('sr3', (1e-6, 1e-2)), ('ddpm', (1e-4, 2e-2))):
+            ref = g['%s/%s/%d' % (flavour, sched, n)]
+            a = np.asarray(O.make_beta_schedule(sched, n, ls, le), dtype=np.float64)
+            b = np.asarray(D.make_beta_schedule(sched, n, ls, le), dtype=np.float64)
+            assert a.shape == ref.shape and np.array_equal(a, ref), (flavour, n, 'oracle')
+            assert b.shape == ref.shape and np.array_equal(b, ref), (flavour, n, 'engine')
+
+
+def test_cosine_schedule_buffers_match_reference():
+    import os
+    from helpers import ROOT
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'schedules.npz'))
+    opt = dict(schedule='cosine', n_timestep=50, linear_start=1e-6, linear_end=1e-2)
+    tab = O.schedule_tables(opt)
+    keys = [k[len('buf/cosine50/'):] for k in g.files if k.startswith('buf/cosine50/')]
+    assert len(keys) == 13
+    for k in keys:
+        assert np.array_equal(tab[k], g['buf/cosine50/' + k]), k
+    # the engine's module registers the same buffers (CPU construction works without a GPU)
+    import model.networks as networks
+    from helpers import opt_for
+    o = opt_for('sr3_tiny', phase='val', gpu=False)
+    netG = networks.define_G(o)
+    netG.set_new_noise_schedule(opt, torch.device('cpu'))
+    sdn = netG.state_dict()
+    for k in keys:
+        if k == 'sqrt_alphas_cumprod_prev':
+            assert np.array_equal(np.asarray(netG.sqrt_alphas_cumprod_prev), g['buf/cosine50/' + k])
+        else:
+            assert np.array_equal(sdn[k].numpy(), g['buf/cosine50/' + k]), k
