@@ -940,12 +940,14 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
   if (rc) return rc;
   if (workspace_bytes < plan->ws_bytes) { set_error("workspace too small"); return SR3_E_NOMEM; }
   const int n = (int)plan->ops.size();
-  std::vector<hipEvent_t> ev(n + 1), mid(n);
-  for (auto& e : ev) SR3_HIP(hipEventCreate(&e));
-  for (auto& e : mid) SR3_HIP(hipEventCreate(&e));
+  std::vector<hipEvent_t> ev(n + 1, nullptr), mid(n, nullptr);
+  for (auto* v : {&ev, &mid})
+    for (auto& e : *v)
+      if (hipError_t err = hipEventCreate(&e); err != hipSuccess && !rc) rc = hip_fail(err, "hipEventCreate");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  rc = run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr,
-                   nullptr, params, static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data(), mid.data());
+  if (!rc)
+    rc = run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, nullptr,
+                     nullptr, params, static_cast<char*>(workspace), eps_out_nchw, batch, st, ev.data(), mid.data());
   if (!rc) {
     hipError_t e = hipEventSynchronize(ev[n]);
     if (e != hipSuccess) rc = hip_fail(e, "hipEventSynchronize");
@@ -954,7 +956,7 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
     int w = 0;
     for (int i = 0; i < n && !rc; ++i) {
       float ms = 0.f;
-      hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+      if (hipError_t e = hipEventElapsedTime(&ms, ev[i], ev[i + 1]); e != hipSuccess) { rc = hip_fail(e, "hipEventElapsedTime"); break; }
       const Op& o = plan->ops[i];
       int kind = (int)o.kind * 10;
       double fl = 0.0;
@@ -971,7 +973,7 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
         fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)(c.C0 + c.C1) * c.ksize * c.ksize + (o.has_x2 ? c.x2_C0 + c.x2_C1 : 0));
         if (o.ksplit > 1) {      // split the op into its GEMM kernel and its split-K reduce kernel
           float a = 0.f;
-          hipEventElapsedTime(&a, ev[i], mid[i]);
+          if (hipError_t e = hipEventElapsedTime(&a, ev[i], mid[i]); e != hipSuccess) { rc = hip_fail(e, "hipEventElapsedTime"); break; }
           red_ms = ms - a;
           ms = a;
         }
@@ -984,8 +986,8 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
     }
     *n_ops = w;
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
-  for (auto& e : mid) (void)hipEventDestroy(e);
+  for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : mid) if (e) (void)hipEventDestroy(e);
   return rc;
 }
 
