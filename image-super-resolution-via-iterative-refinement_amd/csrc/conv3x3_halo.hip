@@ -129,9 +129,15 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     himg[j] = nb;
   }
 
-  f32x4 rh[HI], rw[BR];
+  // weight tiles in flight: the 8-wave split-bf16 kernel prefetches two taps ahead (its taps are ~3x shorter than the
+  // fp32 kernel's, about one L2 round trip), every other instantiation one
+  constexpr bool PF2 = MODE == 1 && NW == 8;
+  constexpr int WSETS = PF2 ? 2 : 1;
+  using SET0 = std::integral_constant<int, 0>;
+  using SET1 = std::integral_constant<int, WSETS - 1>;
+  f32x4 rh[HI], rw[WSETS][BR];
   f32x4 ssa[2], ssb[2];     // scale/shift of this thread's channel quad for image slots 0 / 1
-  bool wok[BR];
+  bool wok[WSETS][BR];
   bool hvalid = false;      // channel quad of the staged chunk is inside Cin
 
   int cur_act = 0;          // prologue of the staged chunk (segment 2 has none)
@@ -203,8 +209,9 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     }
   };
 
-  auto load_w = [&](auto seg2_tag, int chunk, int tap) {
+  auto load_w = [&](auto seg2_tag, auto set_tag, int chunk, int tap) {
     constexpr bool seg2 = decltype(seg2_tag)::value;
+    constexpr int S = decltype(set_tag)::value;
     const int CinS = seg2 ? Cin2 : Cin;
     const float* wp = seg2 ? p.x2_w : p.w;
     constexpr int ntap = seg2 ? 1 : 9;
@@ -214,24 +221,25 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     for (int j = 0; j < BR; ++j) {
       const int n = tile_n * BN + lrow + RPP * j;
       const bool ok = cvalid && n < p.Cout;
-      wok[j] = ok;
+      wok[S][j] = ok;
       const int off = ok ? (n * ntap + tap) * CinS + c : 0;
-      rw[j] = *reinterpret_cast<const f32x4*>(wp + off);
+      rw[S][j] = *reinterpret_cast<const f32x4*>(wp + off);
     }
   };
-  auto store_w = [&](int stage) {
+  auto store_w = [&](auto set_tag, int stage) {
+    constexpr int S = decltype(set_tag)::value;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == 0) {
       float* Bw = wst + stage * WSTAGE;
 #pragma unroll
       for (int j = 0; j < BR; ++j)
-        *reinterpret_cast<f32x4*>(&Bw[(lrow + RPP * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
+        *reinterpret_cast<f32x4*>(&Bw[(lrow + RPP * j) * LDK + kq * 4]) = wok[S][j] ? rw[S][j] : zero;
     } else {
       __bf16* Bb = wst_b + stage * 3 * BN * LDB;
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
         bf16x4 h, m, l;
-        split3(wok[j] ? rw[j] : zero, h, m, l);
+        split3(wok[S][j] ? rw[S][j] : zero, h, m, l);
         const int o = swz(lrow + RPP * j, kq >> 1) + (kq & 1) * 4;
         *reinterpret_cast<bf16x4*>(&Bb[0 * BN * LDB + o]) = h;
         *reinterpret_cast<bf16x4*>(&Bb[1 * BN * LDB + o]) = m;
@@ -314,11 +322,50 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
   // ---- main loop: chunks (halo restage) x 9 taps (weight restage) ---------------------------------
   using SEG1 = std::integral_constant<bool, false>;
   using SEG2 = std::integral_constant<bool, true>;
-  if (c_begin < c_end) {
+  if constexpr (PF2) {
+    // Weight tiles are prefetched two taps ahead; tile tl (linear tap index over chunks x 9) lives in register set
+    // tl & 1, so the loop is unrolled by two to keep the set a compile-time constant.
+    const int ntl = (c_end - c_begin) * 9;
+    auto load_tile = [&](auto set_tag, int tl) {
+      const int ch = tl / 9;
+      load_w(SEG1{}, set_tag, c_begin + ch, tl - ch * 9);
+    };
+    if (ntl > 0) {
+      load_halo(SEG1{}, c_begin);
+      load_tile(SET0{}, 0);
+      store_halo();
+      store_w(SET0{}, 0);
+      if (ntl > 1) load_tile(SET1{}, 1);
+      __syncthreads();
+      int stage = 0;
+      auto body = [&](auto next_set /* holds tile tl + 1 */, auto free_set /* held tile tl, already staged */, int tl) {
+        const int ch = tl / 9, tap = tl - ch * 9;
+        const int chunk = c_begin + ch;
+        const bool more_chunks = chunk + 1 < c_end;
+        const bool last_tap = tap == 8;
+        if (tap == 0 && more_chunks) load_halo(SEG1{}, chunk + 1);     // in flight across the 9 taps of this chunk
+        if (tl + 2 < ntl) load_tile(free_set, tl + 2);
+        const int fr = tap / 3, fs = tap - fr * 3;
+        compute(stage, fr * TWp + fs);
+        if (tl + 1 < ntl) store_w(next_set, stage ^ 1);
+        if (last_tap && more_chunks) {
+          __syncthreads();                          // every wave is done reading the halo tile
+          store_halo();
+        }
+        __syncthreads();
+        stage ^= 1;
+      };
+#pragma unroll 1
+      for (int tl = 0; tl < ntl; tl += 2) {
+        body(SET1{}, SET0{}, tl);
+        if (tl + 1 < ntl) body(SET0{}, SET1{}, tl + 1);
+      }
+    }
+  } else if (c_begin < c_end) {
     load_halo(SEG1{}, c_begin);
-    load_w(SEG1{}, c_begin, 0);
+    load_w(SEG1{}, SET0{}, c_begin, 0);
     store_halo();
-    store_w(0);
+    store_w(SET0{}, 0);
     __syncthreads();
     int stage = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk) {
@@ -328,11 +375,11 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
       for (int tap = 0; tap < 9; ++tap) {
         const bool last_tap = tap == 8;
         const bool more = !last_tap || more_chunks;
-        if (more && !(p.dbg & 2)) load_w(SEG1{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+        if (more && !(p.dbg & 2)) load_w(SEG1{}, SET0{}, last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
         const int fr = tap / 3, fs = tap - fr * 3;
         if (!(p.dbg & 1)) compute(stage, fr * TWp + fs);
         if constexpr (WST == 1) __syncthreads();    // single weight stage: every wave is done with it
-        if (more && !(p.dbg & 2)) store_w(stage ^ (WST - 1));
+        if (more && !(p.dbg & 2)) store_w(SET0{}, stage ^ (WST - 1));
         if (last_tap && more_chunks && !(p.dbg & 2)) {
           if constexpr (WST == 2) __syncthreads();  // every wave is done reading the halo tile
           store_halo();
@@ -346,18 +393,18 @@ void k_conv3x3_halo(const ConvParams p, const HaloGeom g) {
     // ---- segment 2: 1x1 conv of x2, one k-step per chunk (halo centre, its own weights) ------------
     if (do_x2 && nch2 > 0) {
       load_halo(SEG2{}, 0);
-      load_w(SEG2{}, 0, 0);
+      load_w(SEG2{}, SET0{}, 0, 0);
       store_halo();          // the last barrier of the main loop already retired every LDS read
-      store_w(0);
+      store_w(SET0{}, 0);
       __syncthreads();
       int stage = 0;
       for (int chunk = 0; chunk < nch2; ++chunk) {
         const bool more = chunk + 1 < nch2;
-        if (more) { load_halo(SEG2{}, chunk + 1); load_w(SEG2{}, chunk + 1, 0); }
+        if (more) { load_halo(SEG2{}, chunk + 1); load_w(SEG2{}, SET0{}, chunk + 1, 0); }
         compute(stage, TWp + 1);
         if (more) {
           if constexpr (WST == 1) __syncthreads();
-          store_w(stage ^ (WST - 1));
+          store_w(SET0{}, stage ^ (WST - 1));
           if constexpr (WST == 2) __syncthreads();
           store_halo();
         }
