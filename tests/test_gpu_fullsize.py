@@ -113,3 +113,53 @@ def test_config1_ten_step_loop_all_frames():
     assert tuple(m.SR.shape) == (11, 3, 128, 128) and bool(torch.isfinite(m.SR).all())
     vis = m.get_current_visuals(need_LR=False)
     assert tuple(vis['SR'].shape) == (11, 3, 128, 128) and tuple(vis['INF'].shape) == (1, 3, 128, 128)
+
+
+@pytest.mark.parametrize('name', ['sr3_16_128', 'ddpm_128'])
+def test_fullsize_training_step_vs_oracle_autograd(name):
+    """BASELINE.json configs[2] (SR3 16->128) and C5 (DDPM-128) at batch 1, dropout 0: loss and EVERY parameter gradient
+    of the engine's forward + backward against torch autograd over the CPU oracle with the same (gamma | t, z).
+    Tolerances: loss rel 1e-5, gradients normwise rel 1e-4."""
+    from oracle import sr3_oracle as O
+    import model.networks as networks
+    c = CONFIGS[name]
+    opt = make_opt(c)
+    torch.manual_seed(17)
+    netG = networks.define_G(opt)                       # phase 'train': orthogonal init in the reference's order
+    sd = {k: v.clone() for k, v in netG.state_dict().items()}
+    d = G.dev()
+    netG = netG.to(d)
+    netG.set_loss(d)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['train'], d)
+    netG.train()
+    desc = O.desc_from_opt(opt)
+    S = c['size']
+    g = torch.Generator().manual_seed(8)
+    hr = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    sr = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    z = torch.randn(1, 3, S, S, generator=g)
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
+    if c['which'] == 'sr3':
+        gamma = torch.tensor([0.6180339])
+        loss = netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), gamma=gamma)
+        ref_loss = O.p_losses_sr3(sdr, desc, hr, sr, gamma, z, conditional=True)
+    else:
+        t = torch.tensor([1234], dtype=torch.long)
+        loss = netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), t=t)
+        tab = O.schedule_tables(opt['model']['beta_schedule']['train'])
+        ref_loss = O.p_losses_ddpm(sdr, desc, tab, hr, sr, t, z, conditional=False)
+    torch.cuda.synchronize()
+    (ref_loss / hr.numel()).backward()
+    rl = float(ref_loss.detach())
+    assert abs(float(loss) - rl) <= 1e-5 * abs(rl), (float(loss), rl)
+    worst, n = [], 0
+    for key, grad in netG.denoise_fn.named_gradients():
+        ref = sdr['denoise_fn.' + key].grad
+        num, den = (grad.cpu() - ref).norm().item(), max(ref.norm().item(), 1e-12)
+        worst.append((num / den, key, den))
+        n += 1
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[0] > 1e-4 and w[2] > 1e-7]
+    assert n > 150 and not bad, bad[:8]
+    print('%s: training step loss rel err %.1e, worst gradient rel err %.1e (%s) over %d tensors'
+          % (name, abs(float(loss) - rl) / abs(rl), worst[0][0], worst[0][1], n))
