@@ -1,43 +1,43 @@
-"""BaseModel of the drop-in `model` package (reference: model/base_model.py:6-48)."""
+"""BaseModel of the drop-in `model` package: the small host-side base the DDPM wrapper builds on.
+
+Contract kept from the reference (model/base_model.py:6-48): attributes `opt`, `device`, `begin_step`,
+`begin_epoch`; `set_device(x)` moves a tensor, a module, a dict of tensors (in place, None entries kept) or a list of
+tensors to the model's device; `get_network_description(net)` returns (repr, parameter count).  The reference's empty
+hook methods are provided through one table instead of five stubs."""
 import torch
-import torch.nn as nn
+from torch import nn
+
+
+def _to_device(value, device):
+    return value if value is None else value.to(device)
 
 
 class BaseModel(object):
+    #: hooks a subclass overrides; the base versions do nothing (as in the reference)
+    _HOOKS = ('feed_data', 'optimize_parameters', 'get_current_visuals', 'get_current_losses', 'print_network')
+
     def __init__(self, opt):
         self.opt = opt
-        # 'cuda' is HIP on ROCm; the engine itself refuses to run on 'cpu'
-        self.device = torch.device('cuda' if opt['gpu_ids'] is not None else 'cpu')
-        self.begin_step = 0
-        self.begin_epoch = 0
-
-    def feed_data(self, data):
-        pass
-
-    def optimize_parameters(self):
-        pass
-
-    def get_current_visuals(self):
-        pass
-
-    def get_current_losses(self):
-        pass
-
-    def print_network(self):
-        pass
+        # 'cuda' is HIP on ROCm; with gpu_ids unset the object can be built (checkpoint I/O) but the engine refuses to run
+        self.device = torch.device('cpu' if opt['gpu_ids'] is None else 'cuda')
+        self.begin_step = self.begin_epoch = 0
 
     def set_device(self, x):
-        """Move a tensor / module / dict of tensors / list of tensors to self.device."""
         if isinstance(x, dict):
-            for k in list(x.keys()):
-                if x[k] is not None:
-                    x[k] = x[k].to(self.device)
+            x.update({key: _to_device(val, self.device) for key, val in x.items()})
             return x
         if isinstance(x, list):
-            return [None if v is None else v.to(self.device) for v in x]
-        return x.to(self.device)
+            return [_to_device(val, self.device) for val in x]
+        return _to_device(x, self.device)
 
     def get_network_description(self, network):
-        if isinstance(network, nn.DataParallel):
-            network = network.module
-        return str(network), sum(p.numel() for p in network.parameters())
+        net = network.module if isinstance(network, nn.DataParallel) else network
+        return str(net), sum(w.numel() for w in net.parameters())
+
+
+def _noop(self, *args, **kwargs):
+    return None
+
+
+for _name in BaseModel._HOOKS:
+    setattr(BaseModel, _name, _noop)
