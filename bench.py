@@ -269,13 +269,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)              # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('SR3_BENCH_FORCE_DIST'):     # the env knob exercises the collective path on one GPU
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import model.networks as networks
     T = 2000
