@@ -1,53 +1,79 @@
 #!/usr/bin/env python3
-"""bench.py -- SR3 16->128 sampling throughput of the MI355X engine (BASELINE.json metric).
+"""bench.py -- sampling throughput of the MI355X engine on the BASELINE.json configurations.
 
-Workload (BASELINE.json configs[1]): the SR3 16->128 UNet of config/sr_sr3_16_128.json (inner 64,
-mults 1,2,4,8,8, attention at 16x16, 97.8 M fp32 parameters, random init), batch 16 per GPU,
-T = 2000 linear-beta reverse steps.  A *step* is one reverse step p_sample of the whole batch:
-[z ~ N(0,I)] -> UNet forward -> fused x_{t-1} update -> counter decrement, replayed from one
-hipGraph.  The default --steps 2000 times one complete sample; images/s = N * B / (T * t_step).
+Default workload (BASELINE.json configs[1], the one the headline metric is quoted on): the SR3 16->128 UNet of
+config/sr_sr3_16_128.json (inner 64, mults 1,2,4,8,8, attention at 16x16, 97.8 M fp32 parameters, random init),
+batch 16 per GPU, T = 2000 linear-beta reverse steps.  A *step* is one reverse step p_sample of the whole batch:
+[z ~ N(0,I)] -> UNet forward -> fused x_{t-1} update -> counter decrement, replayed from one hipGraph.  The default
+--steps 2000 times one complete sample; images/s = N * B / (T * t_step).  `--config sr3_64_512` (configs[3], batch 4)
+and `--config ddpm_128` (configs[4], batch 32, unconditional) time the other BASELINE.json networks the same way.
 
-One JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (the halo-tile 3x3 conv on v_mfma_f32_32x32x2_f32): algorithmic
-                  FLOPs per launch / average launch duration, measured with HIP events around every
-                  launch of the plan (sr3_unet_forward_profile) right after the timed region.
-  cpu_baseline -- the CPU oracle (oracle/sr3_oracle.py, a port of the reference's algorithm) timed on
-                  this node's host cores on a bounded sample (a few reverse steps at the same batch).
-Multi-GPU: one process per GPU (torch.distributed.run), independent image batches per rank (the
-reverse chains share nothing), no collective in the data path; the timed region is bracketed by
-barrier + synchronize and the MAX over ranks is reported ("scaling": "weak").
+One JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline            -- dominant kernel (a halo-tile 3x3 conv instantiation on v_mfma_f32_32x32x2_f32): algorithmic
+                         FLOPs per launch / average launch duration, measured with HIP events around every launch of
+                         the plan (sr3_unet_forward_profile, on the stream the kernels run on) after the timed region.
+  parity              -- the graph bench.py just timed, replayed once from a fixed (x, cond, t); its eps and x_{t-1}
+                         against the CPU oracle on the same inputs and the same in-graph z (max abs difference).
+  cpu_baseline        -- the reference itself (subprocess importing $SR3_REFERENCE or /root/reference, kind
+                         "reference") or, where that tree does not exist (the GPU box), the CPU oracle (kind "port"),
+                         timed on this node's host cores on a bounded sample; `.train` = training steps per image.
+  torch_rocm_baseline -- the same oracle ops on `cuda` through stock PyTorch-ROCm (MIOpen / rocBLAS): "what you get by
+                         default on this node".  Reported, never the target.
+  train               -- BASELINE.json configs[2] / [4]: training step (p_losses + backward + Adam) images/s.
+Multi-GPU: one process per GPU.  `python bench.py --gpus N` launches the N ranks itself (torch.distributed.run over
+127.0.0.1) when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py --gpus N`
+it uses the launcher's ranks (and refuses a WORLD_SIZE that differs from --gpus).  Sampling: independent image batches
+per rank (the reverse chains share nothing), no collective in the data path; training: RCCL all-reduce of gradient
+buckets overlapped with the backward.  The timed region is bracketed by barrier + synchronize and the MAX over ranks is
+reported ("scaling": "weak").
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import threading
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd'))
-sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
+PROFILE_ROUND = 'r02'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
+
+# The `model` subtrees of the reference's configs (config/sr_sr3_16_128.json:39-77, sr_sr3_64_512.json:39-80,
+# sample_ddpm_128.json:38-79) + the batch sizes BASELINE.json quotes.
+CONFIGS = {
+    'sr3_16_128': dict(which='sr3', unet=dict(in_channel=6, out_channel=3, inner_channel=64, channel_multiplier=[1, 2, 4, 8, 8],
+                                              attn_res=[16], res_blocks=2, dropout=0.2),
+                       beta=(1e-6, 1e-2), size=128, conditional=True, batch=16, train_batch=64, lr=1e-4,
+                       baseline_cfg=1, title='SR3 16->128', ref_json='config/sr_sr3_16_128.json'),
+    'sr3_64_512': dict(which='sr3', unet=dict(in_channel=6, out_channel=3, inner_channel=64, norm_groups=16,
+                                              channel_multiplier=[1, 2, 4, 8, 16], attn_res=[], res_blocks=1, dropout=0),
+                       beta=(1e-6, 1e-2), size=512, conditional=True, batch=4, train_batch=2, lr=3e-6,
+                       baseline_cfg=3, title='SR3 64->512', ref_json='config/sr_sr3_64_512.json'),
+    'ddpm_128': dict(which='ddpm', unet=dict(in_channel=3, out_channel=3, inner_channel=64, channel_multiplier=[1, 1, 2, 2, 4, 4],
+                                             attn_res=[16], res_blocks=2, dropout=0.2),
+                     beta=(1e-4, 2e-2), size=128, conditional=False, batch=32, train_batch=32, lr=1e-4,
+                     baseline_cfg=4, title='DDPM 128x128 (unconditional)', ref_json='config/sample_ddpm_128.json'),
+}
 
 
-def sr3_16_128_opt(n_timestep=2000):
-    """The `model` subtree of the reference's config/sr_sr3_16_128.json (lines 39-77)."""
-    sched = dict(schedule='linear', n_timestep=n_timestep, linear_start=1e-6, linear_end=1e-2)
+def config_opt(name, n_timestep=2000, phase='val'):
+    c = CONFIGS[name]
+    sched = dict(schedule='linear', n_timestep=n_timestep, linear_start=c['beta'][0], linear_end=c['beta'][1])
     return {
-        'phase': 'val', 'gpu_ids': [0], 'distributed': False,
+        'phase': phase, 'gpu_ids': [0], 'distributed': False,
         'path': {'checkpoint': '/tmp', 'resume_state': None},
-        'train': {'optimizer': {'type': 'adam', 'lr': 1e-4}},
+        'train': {'optimizer': {'type': 'adam', 'lr': c['lr']}},
         'model': {
-            'which_model_G': 'sr3', 'finetune_norm': False,
-            'unet': dict(in_channel=6, out_channel=3, inner_channel=64, channel_multiplier=[1, 2, 4, 8, 8],
-                         attn_res=[16], res_blocks=2, dropout=0.2),
+            'which_model_G': c['which'], 'finetune_norm': False, 'unet': dict(c['unet']),
             'beta_schedule': {'train': dict(sched), 'val': dict(sched)},
-            'diffusion': dict(image_size=128, channels=3, conditional=True),
+            'diffusion': dict(image_size=c['size'], channels=3, conditional=c['conditional']),
         },
     }
 
@@ -68,53 +94,218 @@ def usable_cores():
     return max(1, min(n, 64))      # torch's intra-op pool stops scaling (and thrashes) far below 256 threads
 
 
-def cpu_baseline(batch, budget_s=25.0):
-    """Oracle p_sample (UNet forward + update) on the host cores, bounded sample."""
+def reference_root():
+    for p in (os.environ.get('SR3_REFERENCE'), '/root/reference'):
+        if p and os.path.isfile(os.path.join(p, 'model', 'networks.py')) and os.path.realpath(p) != os.path.realpath(PKG):
+            return p
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parity of the timed graph + CPU / stock-PyTorch baselines
+# ---------------------------------------------------------------------------------------------------------------
+def capture_parity_inputs(netG, st, cfg, T):
+    """Replay the graph that was just timed ONCE from a fixed (x, cond, t) and keep what the oracle needs to redo
+    that step on the CPU: inputs, the z the graph drew, the graph's eps and x_{t-1}."""
+    import torch
+    dev = st['img'].device
+    t = T // 2 + 7
+    g = torch.Generator().manual_seed(4242)
+    x = torch.randn(tuple(st['img'].shape), generator=g)
+    cond = (torch.rand(tuple(st['img'].shape), generator=g) * 2 - 1) if st['cond'] is not None else None
+    st['img'].copy_(x)
+    if cond is not None:
+        st['cond'].copy_(cond)
+    st['step'].fill_(t)
+    st['graph'].replay()
+    torch.cuda.synchronize(dev)
+    return dict(t=t, x=x, cond=cond, z=st['z'].cpu(), eps=st['eps'].cpu(), x_next=st['img'].cpu())
+
+
+def oracle_tools(cfg_name, netG):
+    import torch
     from oracle import sr3_oracle as O
-    torch.manual_seed(0)
-    opt = sr3_16_128_opt()
+    opt = config_opt(cfg_name)
     desc = O.desc_from_opt(opt)
+    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
+    sd = {k: v.detach().cpu().clone() for k, v in netG.state_dict().items()}
+    return O, desc, tab, sd, torch
+
+
+def parity_vs_oracle(cfg_name, netG, par):
+    """max |GPU - oracle| of the replayed step (same x, cond, t, z, weights).  Returns (record, oracle seconds, x_ref)."""
+    O, desc, tab, sd, torch = oracle_tools(cfg_name, netG)
+    x, t, B = par['x'], par['t'], par['x'].shape[0]
+    t0 = time.time()
+    with torch.no_grad():
+        # O.p_sample (sr3 diffusion.py:151-174) unrolled so that eps is kept as well
+        if desc['variant'] == 'sr3':
+            level = torch.FloatTensor([tab['sqrt_alphas_cumprod_prev'][t + 1]]).repeat(B, 1)
+        else:
+            level = torch.full((B,), t, dtype=torch.long)
+        inp = torch.cat([par['cond'], x], dim=1) if par['cond'] is not None else x
+        eps_ref = O.unet_forward(sd, desc, inp, level)
+        x_ref = O.p_sample_update(tab, x, eps_ref, t, par['z'])
+    dt = time.time() - t0
+    err_x = float((par['x_next'] - x_ref).abs().max())
+    err_e = float((par['eps'] - eps_ref).abs().max())
+    tol_x = 2e-5 * max(1.0, float(x_ref.abs().max()))
+    tol_e = 2e-5 * max(1.0, float(eps_ref.abs().max()))
+    rec = dict(parity_max_abs=max(err_x, err_e), x_next_max_abs_err=err_x, eps_max_abs_err=err_e,
+               what='one hipGraph-replayed reverse step (the graph that was timed) at t=%d, batch %d: eps and x_{t-1} vs the CPU '
+                    'oracle on the same x, cond, in-graph z and weights' % (t, B),
+               eps_ref_max_abs=float(eps_ref.abs().max()), x_ref_max_abs=float(x_ref.abs().max()),
+               tolerance='2e-5 * max(1, |ref|_inf)', ok=bool(err_x <= tol_x and err_e <= tol_e))
+    return rec, dt, x_ref
+
+
+def cpu_baseline(cfg_name, netG, par, budget_s=25.0, train_batch=4):
+    """Sampling: p_sample steps at the config's batch (the first one doubles as the parity check); training: Adam
+    steps at a reduced batch, per image.  Reference code in a subprocess when its tree is present, else the oracle."""
+    import torch
     ncores = usable_cores()
     torch.set_num_threads(ncores)
-    # random-init weights with the reference's shapes (values do not matter for timing)
-    from sr3_hip import engine as E
-    plan = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
-    sd = {}
-    for e in plan.table:
-        sd['denoise_fn.' + e['name']] = torch.randn(e['shape']) * 0.02
-    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
-    x = torch.randn(batch, 3, 128, 128)
-    sr = torch.rand(batch, 3, 128, 128) * 2 - 1
-    z = torch.randn(batch, 3, 128, 128)
+    B = par['x'].shape[0]
+    out = {}
+    ref = reference_root()
+    parity, t_first, x_ref = parity_vs_oracle(cfg_name, netG, par)       # also the oracle's warm-up at the timed batch
+    out['_parity'] = parity
+    if ref is not None:
+        try:
+            out.update(reference_cpu_baseline(ref, cfg_name, netG, par, ncores, budget_s, train_batch))
+            return out
+        except Exception as e:                                # fall through to the port, but say why
+            out['reference_error'] = '%s: %s' % (type(e).__name__, e)
+    O, desc, tab, sd, _ = oracle_tools(cfg_name, netG)
     times = []
+    x = x_ref
     with torch.no_grad():
-        t0 = time.time()
-        O.p_sample(sd, desc, tab, x[:1], 1999, z[:1], condition_x=sr[:1])   # warm-up (1 image: allocator, oneDNN)
-        warm = time.time() - t0
         n = 0
         start = time.time()
-        while n < 8 and (n == 0 or (time.time() - start) * (n + 1) / n + warm < budget_s):
+        while n < 8 and (n == 0 or (time.time() - start) * (n + 1) / n < budget_s):
             t1 = time.time()
-            x = O.p_sample(sd, desc, tab, x, 1998 - n, z, condition_x=sr)
+            x = O.p_sample(sd, desc, tab, x, par['t'] - 1 - n, par['z'], condition_x=par['cond'])
             times.append(time.time() - t1)
             n += 1
-    if not times:
-        times = [warm]
     t_step = sum(times) / len(times)
-    return dict(value=batch / (2000.0 * t_step), unit='images/s', cores=int(torch.get_num_threads()), kind='port',
-                sample='%d reverse steps (oracle p_sample: UNet forward + update) at batch %d after 1 warm-up, '
-                       '%.2f s/step, extrapolated x2000' % (len(times), batch, t_step))
+    out.update(value=B / (2000.0 * t_step), unit='images/s', cores=int(torch.get_num_threads()), kind='port',
+               sample='%d reverse steps (oracle p_sample: UNet forward + update) at batch %d after 1 warm-up step at the '
+                      'same batch (%.2f s), %.2f s/step, extrapolated x2000' % (len(times), B, t_first, t_step))
+    try:
+        out['train'] = oracle_train_baseline(cfg_name, sd, train_batch, 'cpu', ncores)
+    except Exception as e:
+        out['train'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
 
 
-def roofline_from_profile(netG, x, cond, level, reps=3):
+def oracle_train_baseline(cfg_name, sd, batch, device, cores, steps=3):
+    """1 warm-up + `steps` timed optimize_parameters-equivalents (model/model.py:48-58: zero_grad -> p_losses -> /numel ->
+    backward -> Adam) with torch autograd over the oracle's functional ops on `device`."""
+    import torch
+    from oracle import sr3_oracle as O
+    c = CONFIGS[cfg_name]
+    opt = config_opt(cfg_name, phase='train')
+    desc = O.desc_from_opt(opt)
+    tab = O.schedule_tables(opt['model']['beta_schedule']['train'])
+    params = {k: v.to(device).clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.') and 'inv_freq' not in k)
+              for k, v in sd.items()}
+    optim = torch.optim.Adam([p for p in params.values() if p.requires_grad], lr=c['lr'])
+    S = c['size']
+    g = torch.Generator().manual_seed(9)
+    hr = (torch.rand(batch, 3, S, S, generator=g) * 2 - 1).to(device)
+    sr = (torch.rand(batch, 3, S, S, generator=g) * 2 - 1).to(device)
+    times = []
+    for it in range(steps + 1):
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        t0 = time.time()
+        optim.zero_grad()
+        z = torch.randn_like(hr)
+        if c['which'] == 'sr3':
+            gamma = torch.rand(batch, device=device) * 0.5 + 0.4
+            loss = O.p_losses_sr3(params, desc, hr, sr, gamma, z, conditional=True)
+        else:
+            t = torch.randint(0, 2000, (batch,), device=device)
+            loss = O.p_losses_ddpm(params, desc, tab, hr, sr, t, z, conditional=False)
+        (loss / hr.numel()).backward()
+        optim.step()
+        float(loss)                                           # the reference's .item() (model/model.py:58)
+        if device != 'cpu':
+            torch.cuda.synchronize()
+        if it > 0:
+            times.append(time.time() - t0)
+    t_step = sum(times) / len(times)
+    return dict(value=batch / t_step, unit='images/s', s_per_step=t_step, batch=batch, cores=cores,
+                sample='%d Adam steps at batch %d after 1 warm-up (autograd over the oracle ops on %s; the dropout of the '
+                       'training config is left out of this baseline)' % (len(times), batch, device))
+
+
+def reference_cpu_baseline(ref, cfg_name, netG, par, cores, budget_s, train_batch):
+    """tools/ref_baseline.py in a subprocess: the reference's own `model` package collides with the drop-in's name."""
+    import torch
+    tmp = tempfile.mkdtemp(prefix='sr3_ref_')
+    state = os.path.join(tmp, 'state.pth')
+    torch.save({'sd': {k: v.detach().cpu() for k, v in netG.state_dict().items()}, 'x': par['x'], 'cond': par['cond'],
+                't': par['t']}, state)
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'ref_baseline.py'), '--ref', ref, '--config', cfg_name, '--state', state,
+           '--threads', str(cores), '--budget', str(budget_s), '--train-batch', str(train_batch)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s * 6 + 120)
+    if r.returncode != 0:
+        raise RuntimeError('ref_baseline.py rc %d: %s' % (r.returncode, r.stderr.decode()[-400:]))
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+def torch_rocm_baseline(cfg_name, netG, par, dev, steps=5, train_batch=4):
+    """The same oracle ops on the GPU through stock PyTorch-ROCm (MIOpen convolutions, rocBLAS GEMMs, eager): the
+    'unmodified reference on this node' number for sampling and training.  Also a parity cross-check of the engine."""
+    O, desc, tab, sd, torch = oracle_tools(cfg_name, netG)
+    B = par['x'].shape[0]
+    sdd = {k: v.to(dev) for k, v in sd.items()}
+    x, z = par['x'].to(dev), par['z'].to(dev)
+    cond = None if par['cond'] is None else par['cond'].to(dev)
+    out = {}
+    with torch.no_grad():
+        t0 = time.time()
+        x1 = O.p_sample(sdd, desc, tab, x, par['t'], z, condition_x=cond)     # warm-up: MIOpen find / kernel build
+        torch.cuda.synchronize(dev)
+        warm = time.time() - t0
+        out['max_abs_diff_vs_engine'] = float((x1.cpu() - par['x_next']).abs().max())
+        t0 = time.time()
+        for i in range(steps):
+            x1 = O.p_sample(sdd, desc, tab, x1, par['t'] - 1 - i, z, condition_x=cond)
+        torch.cuda.synchronize(dev)
+        t_step = (time.time() - t0) / steps
+    out.update(value=B / (2000.0 * t_step), unit='images/s', ms_per_step=t_step * 1e3, kind='oracle ops on cuda (stock MIOpen / rocBLAS, eager)',
+               sample='%d reverse steps at batch %d after 1 warm-up step (%.1f s incl. MIOpen find), extrapolated x2000'
+                      % (steps, B, warm))
+    del sdd, x1
+    torch.cuda.empty_cache()
+    try:
+        out['train'] = oracle_train_baseline(cfg_name, sd, train_batch, str(dev), 0)
+        out['train'].pop('cores', None)
+    except Exception as e:
+        out['train'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# roofline of the dominant kernel
+# ---------------------------------------------------------------------------------------------------------------
+def roofline_from_profile(netG, x, cond, reps=3):
     """HIP-event timing of every launch of one forward; aggregates the dominant kernel."""
+    import torch
     from sr3_hip import lib as L
     un = netG.denoise_fn
     plan = un.plan
     lib = L.load()
     B = x.shape[0]
+    if plan.variant == 'sr3':
+        level, tstep = torch.full((B,), 0.5, device=x.device), None
+    else:
+        level, tstep = None, torch.full((B,), 1000, dtype=torch.long, device=x.device)
     wsbuf, need = un._ws.get(plan, B, x.device)
-    out = torch.empty(B, 3, 128, 128, device=x.device)
+    out = torch.empty(B, 3, plan.image_size, plan.image_size, device=x.device)
     max_ops = 4096
     ms = (C.c_float * max_ops)()
     kind = (C.c_int * max_ops)()
@@ -123,9 +314,9 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     agg = {}
     for r in range(reps + 1):
-        L.check(lib.sr3_unet_forward_profile(plan.handle, L.ptr(x), L.ptr(cond), 3, L.ptr(level), None, L.ptr(un.freq),
-                                             L.ptr(un.arena.data), L.ptr(wsbuf), need, L.ptr(out), B, stream, max_ops,
-                                             ms, kind, fl, C.byref(n)))
+        L.check(lib.sr3_unet_forward_profile(plan.handle, L.ptr(x), L.ptr(cond), 0 if cond is None else cond.shape[1],
+                                             L.ptr(level), L.ptr(tstep), L.ptr(un.freq), L.ptr(un.arena.data), L.ptr(wsbuf),
+                                             need, L.ptr(out), B, stream, max_ops, ms, kind, fl, C.byref(n)))
         if r == 0:
             continue      # warm-up
         for i in range(n.value):
@@ -151,10 +342,18 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
                            tflops=(v[1] / (v[0] * 1e-3) / 1e12 if v[0] > 0 and v[1] > 0 else None))
               for k, v in sorted(agg.items())}
     traffic = None
+    counters = None
+    kname = 'sr3::' + names[dom].replace(',', ', ')
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
-        with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as f:
-            traffic = json.load(f)['sr3::' + names[dom].replace(',', ', ')]['hbm_bytes_per_launch']
+        with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_hbm_traffic.json')) as f:
+            traffic = json.load(f)[kname]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
+        pass
+    try:        # SQ counters of the current kernels (MFMA-busy fraction), same provenance
+        with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_sq_counters.json')) as f:
+            sq = json.load(f)
+        counters = {'dominant_kernel': sq.get(kname), 'attention': sq.get('attention')}
+    except (OSError, ValueError):
         pass
     is_split = names[dom].split(',')[4] == '1'
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
@@ -162,40 +361,44 @@ def roofline_from_profile(netG, x, cond, level, reps=3):
     return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
                                                    else ' (v_mfma_f32_32x32x2_f32)'), achieved=achieved,
                 peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic,
-                traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/r01_bench_hbm_pmc.csv',
+                traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/%s_bench_hbm_pmc.csv'
+                             % PROFILE_ROUND,
                 avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,
                 flops_per_launch=flops / launches, share_of_forward_time=(t_ms / reps) / total_ms,
-                all_halo_kernels_tflops=all_tf, by_op_kind=detail)
+                all_halo_kernels_tflops=all_tf, sq_counters=counters, by_op_kind=detail)
 
 
-def split_bf16_leg(netG, cond, T, dev, steps=200):
+def split_bf16_leg(netG, st, T, dev, steps=200):
     """Secondary, NOT the headline: the same reverse step with the opt-in `split_bf16` plan option (halo-tile
     convs with Cout > 64 on v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 terms, six products,
     fp32 accumulate).  Reports its step time and how far its eps is from the exact-fp32 path's on the same input."""
+    import torch
     un = netG.denoise_fn
-    B = cond.shape[0]
+    cond = st['cond']
+    shape = tuple(st['img'].shape)
+    B = shape[0]
     g = torch.Generator(device=dev).manual_seed(77)
-    x = torch.randn(B, 3, 128, 128, device=dev, generator=g)
-    level = torch.full((B, 1), 0.6, device=dev)
-    eps_exact = un(x, level, cond=cond).clone()
+    x = torch.randn(shape, device=dev, generator=g)
+    tm = torch.full((B, 1), 0.6, device=dev) if un.variant == 'sr3' else torch.full((B,), 900, dtype=torch.long, device=dev)
+    eps_exact = un(x, tm, cond=cond).clone()
     un.plan.set_option('split_bf16', 1)
     try:
-        eps_split = un(x, level, cond=cond).clone()
-        shape = tuple(cond.shape)
-        st = netG._loop_state(shape, shape, dev)
-        st['cond'].copy_(cond)
-        st['img'].copy_(torch.randn(shape, device=dev))
-        st['step'].fill_(T - 1)
-        netG._capture(st)
+        eps_split = un(x, tm, cond=cond).clone()
+        st2 = netG._loop_state(shape, None if cond is None else shape, dev)
+        if cond is not None:
+            st2['cond'].copy_(cond)
+        st2['img'].copy_(torch.randn(shape, device=dev))
+        st2['step'].fill_(T - 1)
+        netG._capture(st2)
         for _ in range(5):
-            st['graph'].replay()
+            st2['graph'].replay()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(steps):
-            st['graph'].replay()
+            st2['graph'].replay()
         torch.cuda.synchronize(dev)
         ms = (time.perf_counter() - t0) / steps * 1e3
-        finite = bool(torch.isfinite(st['img']).all().item())
+        finite = bool(torch.isfinite(st2['img']).all().item())
     finally:
         un.plan.set_option('split_bf16', 0)
         netG._loop_cache = {}
@@ -207,18 +410,20 @@ def split_bf16_leg(netG, cond, T, dev, steps=200):
                 note='opt-in plan option split_bf16=1; not used for `value`')
 
 
-def train_leg(dist, world, rank, dev, batch, steps, warmup):
-    """BASELINE.json configs[2]: SR3 16->128 training step (p_losses + backward + Adam, dropout 0.2 as
-    configured), `batch` images per GPU, data parallel with bucketed RCCL all-reduce of the gradients."""
+def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
+    """BASELINE.json configs[2] (SR3 16->128, 64 / GPU) or [4] (DDPM-128, 32 / GPU): training step (p_losses + backward +
+    Adam, dropout as configured), data parallel with bucketed RCCL all-reduce of the gradients."""
     import numpy as np
+    import torch
     import model as Model
-    opt = sr3_16_128_opt()
-    opt['phase'] = 'train'
+    c = CONFIGS[cfg_name]
+    opt = config_opt(cfg_name, phase='train')
     torch.manual_seed(0)
     np.random.seed(1234 + rank)
     m = Model.create_model(opt)
+    S = c['size']
     g = torch.Generator().manual_seed(77 + rank)
-    data = {'HR': torch.rand(batch, 3, 128, 128, generator=g) * 2 - 1, 'SR': torch.rand(batch, 3, 128, 128, generator=g) * 2 - 1}
+    data = {'HR': torch.rand(batch, 3, S, S, generator=g) * 2 - 1, 'SR': torch.rand(batch, 3, S, S, generator=g) * 2 - 1}
     m.feed_data(data)
     for _ in range(warmup):
         m.optimize_parameters()
@@ -240,12 +445,34 @@ def train_leg(dist, world, rank, dev, batch, steps, warmup):
         dt = float(tt.item())
     ms = dt / steps * 1e3
     fl = 3.0 * m.netG.denoise_fn.plan.forward_flops(batch)
-    return {'metric': 'SR3 16->128 training images/sec (p_losses + backward + Adam)', 'value': world * batch / (ms * 1e-3),
+    return {'metric': '%s training images/sec (p_losses + backward + Adam)' % c['title'], 'value': world * batch / (ms * 1e-3),
             'unit': 'images/s', 'steps_per_s': 1e3 / ms, 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
-            'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': 0.2, 'optimizer': 'Adam lr 1e-4',
+            'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': c['unet']['dropout'],
+            'optimizer': 'Adam lr %g' % c['lr'],
             'parallelism': 'dp%d, tail-first 32 MB gradient buckets all-reduced (RCCL) as the backward produces them' % world,
             'tflops_at_3x_forward': fl / (ms * 1e-3) / 1e12,
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launcher
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU, RCCL over 127.0.0.1)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report n_gpus=%d\n' % (n, have, n))
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -253,34 +480,52 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=16, help='images per GPU (BASELINE config: 16)')
+    ap.add_argument('--config', default='sr3_16_128', choices=sorted(CONFIGS),
+                    help='BASELINE.json network: sr3_16_128 (configs[1], the headline; default), sr3_64_512 (configs[3]), ddpm_128 (configs[4])')
+    ap.add_argument('--batch', type=int, default=0, help='images per GPU (default: the BASELINE.json batch of --config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-torch-baseline', action='store_true', help='skip the stock PyTorch-ROCm (MIOpen) leg')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-split-leg', action='store_true', help='skip the secondary split_bf16 measurement')
     ap.add_argument('--split-bf16', action='store_true',
                     help='experiment: run the HEADLINE leg with the split_bf16 plan option (dtype is then reported as '
                          '"f32 via 3xbf16 split MFMA"; the default is the exact-fp32 MFMA path)')
     ap.add_argument('--train-steps', type=int, default=10, help='0 disables the training leg')
-    ap.add_argument('--train-batch', type=int, default=64, help='images per GPU (BASELINE config: 64)')
-    ap.add_argument('--extra-leg-timeout', type=int, default=420,
-                    help='seconds after which the roofline / split / train / cpu legs are abandoned and the line is printed')
+    ap.add_argument('--train-batch', type=int, default=0, help='images per GPU (default: the BASELINE.json batch of --config)')
+    ap.add_argument('--extra-leg-timeout', type=int, default=480,
+                    help='seconds after which the roofline / split / train / baseline legs are abandoned and the line is printed')
     a = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))
+    world = int(env_world or '1')
+    if world != a.gpus and not (a.gpus == 1 and env_world is None):
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks\n' % (a.gpus, world))
+        sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, ROOT)
+    import torch
+    if torch.cuda.device_count() <= local:
+        sys.stderr.write('bench.py: rank %d needs cuda:%d but %d device(s) are visible\n' % (rank, local, torch.cuda.device_count()))
+        sys.exit(2)
     torch.cuda.set_device(local)              # before the process group: RCCL binds its communicator to the current device
     dev = torch.device('cuda', local)
     dist = None
     if world > 1 or os.environ.get('SR3_BENCH_FORCE_DIST'):     # the env knob exercises the collective path on one GPU
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import model.networks as networks
+    cfg = CONFIGS[a.config]
     T = 2000
     torch.manual_seed(0)
-    opt = sr3_16_128_opt(T)
+    opt = config_opt(a.config, T)
     netG = networks.define_G(opt).to(dev)
     netG.set_loss(dev)
     netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], dev)
@@ -288,12 +533,13 @@ def main():
     netG.denoise_fn.plan.set_option('fuse_stats', 1)
     if a.split_bf16:
         netG.denoise_fn.plan.set_option('split_bf16', 1)
-    B = a.batch
+    B = a.batch or cfg['batch']
+    S = cfg['size']
     torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
-    cond = (torch.rand(B, 3, 128, 128, device=dev) * 2 - 1)
-    shape = (B, 3, 128, 128)
-    st = netG._loop_state(shape, shape, dev)
-    st['cond'].copy_(cond)
+    shape = (B, 3, S, S)
+    st = netG._loop_state(shape, shape if cfg['conditional'] else None, dev)
+    if cfg['conditional']:
+        st['cond'].copy_(torch.rand(shape, device=dev) * 2 - 1)
     st['img'].copy_(torch.randn(shape, device=dev))
     st['step'].fill_(T - 1)
     netG._capture(st)
@@ -334,19 +580,21 @@ def main():
 
     # ---- the headline record is complete here; everything below is an extra leg that must never cost the line ----
     flops_step = netG.denoise_fn.plan.forward_flops(B)
+    nparams = sum(e['numel'] for e in netG.denoise_fn.plan.table)
     rec = {
-        'metric': 'SR3 16->128 images/sec (2000-step sample)', 'value': images_per_s, 'unit': 'images/s',
+        'metric': '%s images/sec (2000-step sample)' % cfg['title'], 'value': images_per_s, 'unit': 'images/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 via 3xbf16 split MFMA' if a.split_bf16 else 'f32', 'data': 'synthetic',
-        'config': {'workload': 'SR3 16->128 UNet (reference config/sr_sr3_16_128.json), batch %d per GPU, '
-                               '2000-step p_sample_loop via hipGraph replay; step = one reverse step of the batch; '
-                               'images/s = n_gpus*batch/(2000*t_step)' % B,
-                   'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': 128,
-                   'params': 97807491, 'parallelism': 'independent batches per rank (no collective)',
+        'config': {'workload': '%s UNet (reference %s; BASELINE.json configs[%d]), batch %d per GPU, 2000-step p_sample_loop via '
+                               'hipGraph replay; step = one reverse step of the batch; images/s = n_gpus*batch/(2000*t_step)'
+                               % (cfg['title'], cfg['ref_json'], cfg['baseline_cfg'], B),
+                   'name': a.config, 'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': S,
+                   'params': nparams, 'parallelism': 'independent batches per rank (no collective)',
                    'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
         'step_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,
         'step_frac_of_fp32_mfma_peak': flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        'parity_max_abs': None,
     }
     printed = threading.Lock()
 
@@ -366,32 +614,50 @@ def main():
     timer.daemon = True
     timer.start()
 
-    if rank == 0 and not a.no_roofline:
-        level = torch.full((B,), 0.5, device=dev)
+    par = None
+    if rank == 0:
         try:
-            rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'], level)
+            par = capture_parity_inputs(netG, st, cfg, T)
+        except Exception as e:
+            rec['parity'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0 and not a.no_roofline:
+        try:
+            rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'])
         except Exception as e:
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and not a.no_split_leg and not a.split_bf16:
         try:
-            rec['split_bf16'] = split_bf16_leg(netG, st['cond'], T, dev)
+            rec['split_bf16'] = split_bf16_leg(netG, st, T, dev)
         except Exception as e:
             rec['split_bf16'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    # free the sampling state (graph, workspace) -- the training workspace is ~18 GB at batch 64
+    st['graph'] = None
+    graph = None
+    netG._loop_cache = {}
+    torch.cuda.empty_cache()
     if a.train_steps > 0:
-        # free the sampling state first (graph, workspace) -- the training workspace is ~18 GB at batch 64
-        st['graph'] = None
-        netG._loop_cache = {}
-        torch.cuda.empty_cache()
         try:
-            train = train_leg(dist, world, rank, dev, a.train_batch, a.train_steps, 2)
+            train = train_leg(a.config, dist, world, rank, dev, a.train_batch or cfg['train_batch'], a.train_steps, 2)
         except Exception as e:                      # the headline line must survive a failing extra leg
             train = {'error': '%s: %s' % (type(e).__name__, e)}
         rec['train'] = train
-    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        torch.cuda.empty_cache()
+    if rank == 0 and par is not None and not a.no_cpu_baseline:
         try:
-            rec['cpu_baseline'] = cpu_baseline(B)
+            if world == 1:
+                cb = cpu_baseline(a.config, netG, par)
+                rec['parity'] = cb.pop('_parity')
+                rec['cpu_baseline'] = cb
+            else:                                   # N > 1: the parity check only (baselines are an N = 1 leg)
+                rec['parity'] = parity_vs_oracle(a.config, netG, par)[0]
+            rec['parity_max_abs'] = rec['parity']['parity_max_abs']
         except Exception as e:
             rec['cpu_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and par is not None and not a.no_torch_baseline:
+        try:
+            rec['torch_rocm_baseline'] = torch_rocm_baseline(a.config, netG, par, dev)
+        except Exception as e:
+            rec['torch_rocm_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     timer.cancel()
     emit()
     if dist:

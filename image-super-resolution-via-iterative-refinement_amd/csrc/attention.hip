@@ -209,12 +209,10 @@ int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStre
   const int npan = (C + 127) / 128;
   int zsplit = 1;
   while (zsplit * 2 <= npan && (long)qblocks * B * zsplit < 256) zsplit *= 2;
-  static size_t attr_max[3] = {0, 0, 0};
+  static std::atomic<uint64_t> attr_done[3];
   auto kern = nstage == 2 ? k_attention<2> : k_attention<1>;
-  if (smem > attr_max[nstage]) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_max[nstage] = smem;
-  }
+  // the attribute is an upper bound: allow the whole 160 KB LDS once per (instantiation, device)
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024, attr_done[nstage])) return rc;
   hipLaunchKernelGGL(kern, dim3(qblocks, B, zsplit), dim3(256), smem, st, qkv, N, C, out);
   SR3_LAUNCH_CHECK("k_attention");
   return SR3_OK;

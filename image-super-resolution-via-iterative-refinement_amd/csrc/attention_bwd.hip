@@ -340,13 +340,11 @@ int attention_backward(const float* qkv, const float* dout, const float* out_fwd
     smem = bytes(KB, stage2);
   }
   SR3_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * N * 3 * C * sizeof(float), st));
-  static size_t attr_max[3] = {0, 0, 0};
+  static std::atomic<uint64_t> attr_done[3];
   const int which = KB ? 2 : nstage - 1;
   auto kern = KB ? k_attention_bwd<2, true> : (nstage == 2 ? k_attention_bwd<2, false> : k_attention_bwd<1, false>);
-  if (smem > attr_max[which]) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    attr_max[which] = smem;
-  }
+  // the attribute is an upper bound: allow the whole LDS once per (instantiation, device)
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), (int)lds_max, attr_done[which])) return rc;
   hipLaunchKernelGGL(kern, dim3((N + 31) / 32, B), dim3(256), smem, st, qkv, dout, out_fwd, N, C, KB, dqkv);
   SR3_LAUNCH_CHECK("k_attention_bwd");
   return SR3_OK;

@@ -521,12 +521,9 @@ int launch_halo(const ConvParams& p, const HaloGeom& g, hipStream_t st) {
   constexpr int smem_main = MODE == 0 ? (HP_MAX * 36 + 2 * BN * 36) * 4 : (3 * HP_MAX * 32 + WST * 3 * BN * 32) * 2;
   constexpr int smem_epi = NW * 32 * 68 * 4 + WAVES_M * 2 * BN * 2 * 8;
   constexpr int smem = smem_main > smem_epi ? smem_main : smem_epi;
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = k_conv3x3_halo<WAVES_M, WAVES_N, X2, DROP, MODE, NI>;
-  if (!attr_set) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc;
   const int tiles_n = (p.Cout + BN - 1) / BN;
   const int groups = (p.B + g.NB - 1) / g.NB;
   dim3 grid((unsigned)(tiles_n * g.tiles_w * g.tiles_h * groups), p.ksplit);

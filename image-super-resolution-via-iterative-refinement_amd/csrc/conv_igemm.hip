@@ -305,13 +305,10 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 template <int BM, int BN, int TAPS>
 int launch_conv(const ConvParams& p, hipStream_t st) {
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   constexpr int smem = 2 * (BM + BN) * 36 * 4;
   auto kern = k_conv_igemm<BM, BN, TAPS>;
-  if (!attr_set) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc;
   const int M = p.B * p.Ho * p.Wo;
   dim3 grid(cdiv(M, BM) * cdiv(p.Cout, BN), p.ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);

@@ -1038,6 +1038,30 @@ int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int
   c.x2_src0 = x2_src0; c.x2_src1 = x2_src1; c.x2_C0 = x2_C0; c.x2_C1 = x2_src1 ? x2_C1 : 0; c.x2_w = x2_w; c.x2_bias = x2_bias;
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
 }
+int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cout, const float* w, const float* bias,
+                         const float* ss, int act, const float* film, int film_stride, const float* res0, int RC0,
+                         const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1, const float* x2_w,
+                         const float* x2_bias, float* out, double* out_stats, int tile_cfg, int ksplit, void* scratch,
+                         size_t scratch_bytes, unsigned drop_seed, float drop_p, void* stream) {
+  if (!src0 || !w || !out || !ss) { set_error("null argument"); return SR3_E_BADARG; }
+  if (drop_p < 0.f || drop_p >= 1.f) { set_error("drop_p out of range"); return SR3_E_BADARG; }
+  ConvParams c;
+  memset(&c, 0, sizeof(c));
+  c.src0 = src0; c.C0 = C0;
+  c.B = B; c.Hs = H; c.Ws = W; c.stride = 1; c.ksize = 3; c.Ho = H; c.Wo = W;
+  c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
+  c.res0 = res0; c.RC0 = res0 ? RC0 : 0;
+  c.out = out; c.ostat = out_stats; c.ksplit = 1;
+  if (x2_src0) {
+    if (!x2_w) { set_error("x2_src0 needs x2_w"); return SR3_E_BADARG; }
+    c.x2_src0 = x2_src0; c.x2_src1 = x2_src1; c.x2_C0 = x2_C0; c.x2_C1 = x2_src1 ? x2_C1 : 0; c.x2_w = x2_w; c.x2_bias = x2_bias;
+  }
+  // same mapping p -> (threshold, scale) as sr3_train_step
+  c.drop_seed = drop_seed;
+  c.drop_thresh = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
+  c.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
+}
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit) {
   ConvParams c;
   memset(&c, 0, sizeof(c));

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 
+#include <atomic>
+
 #include "../../include/sr3_mi355x.h"
 
 namespace sr3 {
@@ -25,6 +27,19 @@ int hip_fail(hipError_t e, const char* what);
     hipError_t _e = hipGetLastError();                  \
     if (_e != hipSuccess) return sr3::hip_fail(_e, name); \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: remember which devices a kernel instantiation has
+// been prepared on (one bit per device ordinal) so a process that drives several GPUs -- the reference's single-process
+// DataParallel layout -- sets it on each of them.  `done` is a function-local static of the launcher.
+inline int ensure_max_lds(const void* kern, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  SR3_HIP(hipGetDevice(&dev));
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return SR3_OK;
+  SR3_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.fetch_or(bit, std::memory_order_release);
+  return SR3_OK;
+}
 
 // ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
 // Activations are NHWC fp32.  The input is the *virtual* channel concat of up to two sources,

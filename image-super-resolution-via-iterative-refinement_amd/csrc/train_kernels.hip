@@ -5,6 +5,10 @@
 // the fused Adam update.  The contractions (dgrad, wgrad, attention backward) live in
 // conv3x3_halo.hip / conv_igemm.hip (reused with transformed weights), wgrad.hip and
 // attention_bwd.hip.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "sr3_common.h"
 #include "train.h"
 
@@ -278,9 +282,8 @@ __global__ __launch_bounds__(64) void k_sum_parts(const double* __restrict__ par
 // T12: fused Adam over the whole parameter arena (torch.optim.Adam defaults, model/model.py:39-40):
 // m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                               float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
-                                               float bc1, float bc2_sqrt) {
-  const float step = lr / bc1;
+                                               float* __restrict__ v, size_t n4, float w1, float b2, float w2, float eps,
+                                               float step, float bc2_sqrt) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pv = *reinterpret_cast<f32x4*>(p + i * 4);
     const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
@@ -288,8 +291,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      mv[e] = mv[e] + (gv[e] - mv[e]) * (1.0f - b1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
-      vv[e] = vv[e] * b2 + (1.0f - b2) * gv[e] * gv[e];
+      mv[e] = mv[e] + (gv[e] - mv[e]) * w1;                     // torch: exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = vv[e] * b2 + w2 * gv[e] * gv[e];                  //        exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
       const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
       pv[e] = pv[e] - step * (mv[e] / denom);
     }
@@ -447,9 +450,25 @@ int l1_loss_grad(const float* z, const float* e, int B, int Cc, int HW, int CP, 
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int step,
               hipStream_t st) {
   if (n & 3) { set_error("adam: n %% 4"); return SR3_E_BADARG; }
-  const float bc1 = 1.0f - powf(b1, (float)step);
-  const float bc2s = sqrtf(1.0f - powf(b2, (float)step));
-  hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, lr, b1, b2, eps, bc1, bc2s);
+  // torch.optim.Adam evaluates 1 - beta, the bias corrections and the step size as Python floats (double) and rounds
+  // each ONCE to fp32 when it meets the tensor.  The ABI carries fp32 hyper-parameters, so first recover the decimal the
+  // caller meant (0.9f -> 0.9, 1e-4f -> 1e-4): the shortest decimal that rounds back to the same float.
+  auto meant = [](float f) {
+    char buf[40];
+    for (int prec = 6; prec <= 9; ++prec) {
+      snprintf(buf, sizeof(buf), "%.*g", prec, (double)f);
+      const double d = strtod(buf, nullptr);
+      if ((float)d == f) return d;
+    }
+    return (double)f;
+  };
+  const double b1d = meant(b1), b2d = meant(b2), lrd = meant(lr);
+  const double bc1 = 1.0 - pow(b1d, (double)step);
+  const double bc2 = 1.0 - pow(b2d, (double)step);
+  const float step_size = (float)(lrd / bc1);
+  const float bc2s = (float)sqrt(bc2);
+  hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, (float)(1.0 - b1d), (float)b2d,
+                     (float)(1.0 - b2d), (float)meant(eps), step_size, bc2s);
   SR3_LAUNCH_CHECK("k_adam");
   return SR3_OK;
 }

@@ -341,12 +341,9 @@ void wgrad_geometry(const ConvParams& c, int* tn, int* tc, int* msplit, int* cps
 template <int TN, int TC>
 int launch_wgrad(const WgradParams& p, int msplit, int cps, hipStream_t st) {
   constexpr int smem = 2 * 32 * (TN + 4 + TC + 4) * 4;
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_done{0};
   auto kern = k_conv_wgrad<TN, TC>;
-  if (!attr_set) {
-    SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc;
   const int Cin = p.c.C0 + p.c.C1;
   const int taps = p.c.ksize * p.c.ksize;
   dim3 grid(cdivw(p.c.Cout, TN) * cdivw(Cin, TC), taps, msplit);
@@ -383,11 +380,8 @@ int conv_wgrad(const WgradParams& p, hipStream_t st) {
   int rc;
   if (wgrad9_ok(c)) {
     constexpr int smem9 = 2 * (32 + 102) * 68 * 4;
-    static bool attr9 = false;
-    if (!attr9) {
-      SR3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad9), hipFuncAttributeMaxDynamicSharedMemorySize, smem9));
-      attr9 = true;
-    }
+    static std::atomic<uint64_t> attr9_done{0};
+    if (int rc9 = ensure_max_lds(reinterpret_cast<const void*>(k_conv_wgrad9), smem9, attr9_done)) return rc9;
     dim3 grid(cdivw(c.Cout, 64) * cdivw(Cin, 64), 1, ms);
     hipLaunchKernelGGL(k_conv_wgrad9, grid, dim3(256), smem9, st, c.src0, Cin, p.dy, c.Cout, c.B, c.Ho, c.Wo, ilog2w(c.Wo),
                        ms > 1 ? p.slabs : p.dw, cps);

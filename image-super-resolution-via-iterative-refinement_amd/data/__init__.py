@@ -18,12 +18,17 @@ class DeviceBatches(object):
         self.min_max = min_max
         self.dataset = loader.dataset
         self.batch_size = loader.batch_size
+        self.epoch = 0               # reshuffles a rank-sharded sampler every pass (DistributedSampler.set_epoch)
 
     def __len__(self):
         return len(self.loader)
 
     def __iter__(self):
         import data.util as Util
+        sampler = getattr(self.loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(self.epoch)
+        self.epoch += 1
         for batch in self.loader:
             flip = batch.pop('flip', None)
             out = {}
@@ -35,10 +40,29 @@ class DeviceBatches(object):
             yield out
 
 
+def _dp():
+    """(rank, world) of the data-parallel job this process belongs to; (0, 1) outside torch.distributed."""
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_rank(), tdist.get_world_size()
+    return 0, 1
+
+
 def create_dataloader(dataset, dataset_opt, phase, device=None):
-    '''create dataloader '''
+    '''create dataloader.  Data parallel (one process per GPU): `batch_size` stays the GLOBAL batch of the config, as
+    under the reference's nn.DataParallel, which scatters each loader batch over the GPUs (model/networks.py:113-115);
+    every rank draws batch_size / world samples per step from its own disjoint shard of the (shuffled) index list.'''
     if phase == 'train':
-        loader = torch.utils.data.DataLoader(dataset, batch_size=dataset_opt['batch_size'], shuffle=dataset_opt['use_shuffle'],
+        rank, world = _dp()
+        bs, sampler, shuffle = dataset_opt['batch_size'], None, dataset_opt['use_shuffle']
+        if world > 1:
+            if bs % world:
+                raise ValueError('batch_size %d is not divisible by the %d data-parallel ranks' % (bs, world))
+            bs //= world
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank,
+                                                                      shuffle=bool(shuffle), drop_last=False)
+            shuffle = False
+        loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=shuffle, sampler=sampler,
                                              num_workers=dataset_opt['num_workers'], pin_memory=True)
     elif phase == 'val':
         loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)

@@ -29,9 +29,13 @@ class DDPM(BaseModel):
         if self.opt['phase'] == 'train':
             self.netG.train()
             if opt['model']['finetune_norm']:
-                # the reference looks for parameter names containing 'transformer', which never
-                # exist: nothing is optimised in that mode
-                logger.info('finetune_norm: no parameter name contains "transformer"; nothing to optimise')
+                # model/model.py:26-35: every parameter is frozen and only names containing 'transformer' are
+                # optimised -- no such name exists in either UNet, so the reference hands
+                # torch.optim.Adam an empty list, which raises.  Same outcome here, same message.
+                names = [k for k, _ in self.netG.named_parameters() if k.find('transformer') >= 0]
+                if not names:
+                    raise ValueError('optimizer got an empty parameter list')
+                raise NotImplementedError('finetune_norm over %d "transformer" parameters' % len(names))
             from sr3_hip.optim import make_optimizer
             self.optG = make_optimizer(self.netG, lr=opt['train']['optimizer']['lr'])
             self.log_dict = OrderedDict()
@@ -47,7 +51,10 @@ class DDPM(BaseModel):
         # forward + backward run inside the engine; the gradients already carry the 1/(b*c*h*w) factor
         l_pix = self.netG(self.data)
         b, c, h, w = self.data['HR'].shape
-        l_pix = l_pix.sum() / int(b * c * h * w)
+        # data parallel: the engine returns the loss summed over ALL ranks, so normalise by the global element count
+        # (the reference's `l_pix.sum() / int(b*c*h*w)` over DataParallel's gathered per-replica sums, :52-53)
+        from sr3_hip.dist import dp_world_size
+        l_pix = l_pix.sum() / int(b * c * h * w * dp_world_size(self.netG.denoise_fn))
         self.optG.step()
         self.log_dict['l_pix'] = l_pix.item()
 

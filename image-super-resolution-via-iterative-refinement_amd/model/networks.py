@@ -9,12 +9,11 @@ import logging
 logger = logging.getLogger('base')
 
 
-def init_weights(net, init_type='orthogonal', scale=1, std=0.02):
-    """Only the scheme define_G actually uses (orthogonal, networks.py:110-112) is provided."""
+def init_weights(net, init_type='kaiming', scale=1, std=0.02):
+    """model/networks.py:58-77: `scale` applies to 'kaiming', `std` to 'normal'; define_G uses 'orthogonal'.  The draws
+    happen in the reference's `net.apply` order (sr3_hip.nn.EngineUNet.init_scheme)."""
     logger.info('Initialization method [{:s}]'.format(init_type))
-    if init_type != 'orthogonal':
-        raise NotImplementedError('initialization method [{:s}] not implemented'.format(init_type))
-    net.denoise_fn.init_orthogonal()
+    net.denoise_fn.init_scheme(init_type, scale=scale, std=std)
 
 
 def define_G(opt):

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import engine as E
 from . import lib as L
 
 
@@ -137,7 +138,7 @@ class EngineDiffusion(nn.Module):
         tt = t if torch.is_tensor(t) else torch.full((b,), int(t), dtype=torch.long, device=x.device)
         return self.denoise_fn(x, tt, cond=condition_x)
 
-    def p_mean_variance(self, x, t, clip_denoised=True, condition_x=None):
+    def p_mean_variance(self, x, t, clip_denoised: bool, condition_x=None):
         if not clip_denoised:
             raise NotImplementedError('clip_denoised=False is never used by the reference callers')
         eps = self._eps(x, t, condition_x)
@@ -149,8 +150,9 @@ class EngineDiffusion(nn.Module):
         return mean, self._coef('posterior_log_variance_clipped', t, x)
 
     @torch.no_grad()
-    def p_sample(self, x, t, clip_denoised=True, repeat_noise=False, condition_x=None, noise=None):
-        """One reverse step; returns a new tensor (x is left untouched, as in the reference)."""
+    def _p_sample(self, x, t, clip_denoised=True, repeat_noise=False, condition_x=None, noise=None):
+        """One reverse step; returns a new tensor (x is left untouched, as in the reference).  The public `p_sample`
+        of each variant (model/{sr3,ddpm}_modules/diffusion.py) carries the reference's own parameter list."""
         if not clip_denoised:
             raise NotImplementedError('clip_denoised=False is never used by the reference callers')
         x = x.contiguous()
@@ -170,14 +172,17 @@ class EngineDiffusion(nn.Module):
 
     # ---- the reverse loop ------------------------------------------------------------------------
     def _loop_state(self, shape, cond_shape, dev):
+        # a captured graph bakes in the arena, the freq table and the workspace pointer and the plan's launch list:
+        # key on all of them (plan.generation changes with every set_option); the workspace is private to the state
+        un = self.denoise_fn
         key = (tuple(shape), None if cond_shape is None else tuple(cond_shape), str(dev), self.num_timesteps,
-               self.denoise_fn.arena.data_ptr(), self.denoise_fn.plan.options.get('split_bf16', 0))
+               un.arena.data_ptr(), un.freq.data_ptr(), un.plan.generation)
         st = self._loop_cache.get(key)
         if st is None:
             st = dict(img=torch.empty(shape, device=dev), z=torch.empty(shape, device=dev),
                       eps=torch.empty(shape, device=dev),
                       cond=None if cond_shape is None else torch.empty(cond_shape, device=dev),
-                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None)
+                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, ws=E.Workspace())
             self._loop_cache = {key: st}       # keep one shape alive at a time
         return st
 
@@ -185,7 +190,7 @@ class EngineDiffusion(nn.Module):
         if draw_noise:
             st['z'].normal_()
         self.denoise_fn(st['img'], None, cond=st['cond'], level_table=self._level_table, step_dev=st['step'],
-                        out=st['eps'])
+                        out=st['eps'], ws=st['ws'])
         self._step_update(st['img'], st['eps'], st['z'], step_dev=st['step'])
         L.check(L.load().sr3_step_decrement(L.ptr(st['step']), self._stream(st['img'].device)))
 
@@ -212,7 +217,7 @@ class EngineDiffusion(nn.Module):
         st['graph'] = g
 
     @torch.no_grad()
-    def p_sample_loop(self, x_in, continous=False, x_T=None, noise_seq=None):
+    def p_sample_loop(self, x_in, continous=False, *, x_T=None, noise_seq=None):
         """sr3 diffusion.py:176-200 / ddpm :200-230.  Extensions (used by the parity tests): `x_T`
         injects the initial draw, `noise_seq[i]` the noise consumed at step i."""
         dev = self.betas.device
@@ -284,7 +289,7 @@ class EngineDiffusion(nn.Module):
                                       self._stream(x_start.device)))
         return out
 
-    def q_sample(self, x_start, t_or_gamma, noise=None):
+    def _q_sample(self, x_start, t_or_gamma, noise=None):
         if noise is None:
             noise = torch.randn_like(x_start)
         if self.variant == 'sr3':
@@ -293,7 +298,7 @@ class EngineDiffusion(nn.Module):
         t = t_or_gamma.long()
         return self._q_sample_coef(x_start, self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t], noise)
 
-    def p_losses(self, x_in, noise=None, gamma=None, t=None, drop_seed=None):
+    def p_losses(self, x_in, noise=None, *, gamma=None, t=None, drop_seed=None):
         """sr3 diffusion.py:221-246 / ddpm :278-294.  Draws (t, gamma, z) exactly as the reference does
         (numpy global RNG for the SR3 level, torch RNG for z / the DDPM timesteps) unless injected, then
         runs forward + backward in one engine call: returns the sum-reduced L1 loss (0-dim device tensor)

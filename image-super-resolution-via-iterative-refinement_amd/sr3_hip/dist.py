@@ -11,6 +11,15 @@ import time
 import torch
 
 
+def dp_world_size(unet=None):
+    """Ranks that share one training step (1 outside torch.distributed); `unet.force_dp` keeps the collective path
+    on with a single rank (tests)."""
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        return tdist.get_world_size()
+    return 1
+
+
 def shard_range(n_items, rank, world):
     """Contiguous, balanced [lo, hi) of n_items for this rank (first n_items % world ranks get one extra)."""
     base, extra = divmod(n_items, world)

@@ -51,6 +51,7 @@ class Plan(object):
         L.check(self.lib.sr3_plan_create(C.byref(self.desc), C.byref(h)))
         self.handle = h
         self.options = {}          # plan options set through set_option (key -> value)
+        self.generation = 0        # bumped by every set_option: part of the reverse-loop graph cache key
         self.param_floats = int(self.lib.sr3_plan_param_floats(h))
         self.table = []
         pi = L.ParamInfo()
@@ -72,6 +73,7 @@ class Plan(object):
         if rc < 0:
             L.check(rc)
         self.options[key] = int(value)
+        self.generation += 1       # anything compiled / captured against the previous options is stale
         return rc
 
     def workspace_bytes(self, batch):

@@ -78,6 +78,8 @@ SIGNATURES = {
                           _I, _I, _P, _Z, _P]),
     'sr3_block_conv_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _I,
                                 _I, _P, _Z, _P]),
+    'sr3_conv_dropout_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P,
+                                  _I, _I, _P, _Z, C.c_uint, C.c_float, _P]),
     'sr3_conv_scratch_bytes': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'sr3_groupnorm_stats_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'sr3_groupnorm_stats_slices': (_I, [_I, _I, _I]),

@@ -58,8 +58,12 @@ class EngineUNet(nn.Module):
                 nn.init.uniform_(t, -bound, bound)
                 v.copy_(t)
 
-    def init_orthogonal(self):
-        """weights_init_orthogonal (model/networks.py:42-55) in `net.apply` order."""
+    def init_scheme(self, init_type='orthogonal', scale=1, std=0.02):
+        """weights_init_normal / _kaiming / _orthogonal (model/networks.py:14-55) over every Conv2d / Linear, drawn in
+        `net.apply` order so a torch seed gives the reference's weights; biases are zeroed, GroupNorm is left alone
+        (the reference's BatchNorm2d branch never matches a module of these networks)."""
+        if init_type not in ('normal', 'kaiming', 'orthogonal'):
+            raise NotImplementedError('initialization method [{:s}] not implemented'.format(init_type))
         for e in self.plan.table:
             name = e['name']
             if _is_norm(name):
@@ -67,10 +71,19 @@ class EngineUNet(nn.Module):
             v = self.plan.view(self.arena.data, e)
             if len(e['shape']) >= 2:
                 t = torch.empty(e['shape'], dtype=torch.float32)
-                nn.init.orthogonal_(t, gain=1)
+                if init_type == 'orthogonal':
+                    nn.init.orthogonal_(t, gain=1)
+                elif init_type == 'normal':
+                    nn.init.normal_(t, 0.0, std)
+                else:
+                    nn.init.kaiming_normal_(t, a=0, mode='fan_in')
+                    t *= scale
                 v.copy_(t.to(v.device))
             else:
                 v.zero_()
+
+    def init_orthogonal(self):
+        self.init_scheme('orthogonal')
 
     # ---- parameter / state-dict surface --------------------------------------------------------
     def named_parameters(self, prefix='', recurse=True, remove_duplicate=True):
@@ -122,17 +135,19 @@ class EngineUNet(nn.Module):
                     unexpected_keys.append(k)
 
     # ---- forward ---------------------------------------------------------------------------
-    def forward(self, x, time, cond=None, level_table=None, step_dev=None, out=None):
+    def forward(self, x, time, *, cond=None, level_table=None, step_dev=None, out=None, ws=None):
         """eps = UNet(x, time).  `x` may already contain the conditioning channels (reference call
         convention `denoise_fn(torch.cat([cond, x], 1), level)`), or they can be passed separately as
-        `cond`, which the input conv reads as a virtual concat (nothing is materialised)."""
+        `cond`, which the input conv reads as a virtual concat (nothing is materialised).  `ws`: a caller-owned
+        engine.Workspace (the captured reverse loop keeps its own so no other call can move the buffer its graph
+        has baked in)."""
         kw = {}
         if step_dev is None:
             if self.variant == 'sr3':
                 kw['noise_level'] = time
             else:
                 kw['timestep'] = time
-        return E.unet_forward(self.plan, self.arena.data, self.freq, self._ws, x, cond=cond,
+        return E.unet_forward(self.plan, self.arena.data, self.freq, self._ws if ws is None else ws, x, cond=cond,
                               level_table=level_table, step_dev=step_dev, out=out, **kw)
 
     # ---- training step (forward + backward inside the engine) ------------------------------------
@@ -160,8 +175,8 @@ class EngineUNet(nn.Module):
         # data parallel (one process per GPU): gradients are summed over ranks, so the 1/(b c h w) factor
         # uses the GLOBAL batch (model/model.py:52-53 under DataParallel); buckets reduce as they get ready
         import torch.distributed as tdist
-        dp = tdist.is_available() and tdist.is_initialized() and \
-            (tdist.get_world_size() > 1 or getattr(self, 'force_dp', False))
+        from .dist import dp_world_size
+        dp = dp_world_size() > 1 or (getattr(self, 'force_dp', False) and tdist.is_available() and tdist.is_initialized())
         n_marks, offs, evs = 0, None, None
         if dp:
             from .dist import GradReducer

@@ -209,6 +209,16 @@ int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int
                        int film_stride, const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1,
                        const float* x2_w, const float* x2_bias, float* out, double* out_stats, int tile_cfg,
                        int ksplit, void* scratch, size_t scratch_bytes, void* stream);
+/* Train-mode `Block` (unet.py:80-91 with nn.Dropout active, :86): out = conv3x3(dropout(act(src0))) + bias + film
+ *   [+ residual res0] [+ conv1x1(x2_src0|x2_src1) + x2_bias], the op sr3_train_step launches for every block2.
+ * Mask: NHWC element i of the activated input is kept iff hash32(i * 0x9E3779B9 + drop_seed) >= drop_p * 2^32 and
+ * scaled by 1 / (1 - drop_p) (drop_seed is the per-layer seed).  Single source, no upsampling; x2_* may be NULL. */
+int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cout, const float* w_ohwi,
+                         const float* bias, const float* ss, int act, const float* film, int film_stride,
+                         const float* res0, int RC0, const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1,
+                         const float* x2_w, const float* x2_bias, float* out, double* out_stats, int tile_cfg,
+                         int ksplit, void* scratch, size_t scratch_bytes, unsigned drop_seed, float drop_p,
+                         void* stream);
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit);
 /* nn.GroupNorm statistics (unet.py:84,119) as PARTIAL per-(image, channel) {sum, sumsq} in double of
  * an NHWC tensor: stat[B][T][C][2] with T = sr3_groupnorm_stats_slices(B, HW, C).  Plain stores (no

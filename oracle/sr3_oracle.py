@@ -85,7 +85,7 @@ def swish(x):
 def positional_encoding(noise_level, dim):
     """model/sr3_modules/unet.py:18-31 (noise_level: (B,1) -> (B,1,dim))"""
     count = dim // 2
-    step = torch.arange(count, dtype=noise_level.dtype) / count
+    step = torch.arange(count, dtype=noise_level.dtype, device=noise_level.device) / count
     enc = noise_level.unsqueeze(1) * torch.exp(-math.log(1e4) * step.unsqueeze(0))
     return torch.cat([torch.sin(enc), torch.cos(enc)], dim=-1)
 
@@ -93,7 +93,7 @@ def positional_encoding(noise_level, dim):
 def time_embedding(t, dim, inv_freq=None):
     """model/ddpm_modules/unet.py:19-34 (t: (B,) int64 -> (B,dim))"""
     if inv_freq is None:
-        inv_freq = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * (-math.log(10000) / dim))
+        inv_freq = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32, device=t.device) * (-math.log(10000) / dim))
     s = torch.outer(t.reshape(-1).float(), inv_freq)
     return torch.cat([s.sin(), s.cos()], dim=-1).view(*t.shape, dim)
 
@@ -106,10 +106,11 @@ def hash32(x):
     return x
 
 
-def dropout_mask(shape_nchw, p, seed, key):
-    """Mask * 1/(1-p) the engine applies to an activated NCHW tensor (element index = NHWC linear index)."""
+def dropout_mask(shape_nchw, p, seed, key, b_off=0):
+    """Mask * 1/(1-p) the engine applies to an activated NCHW tensor (element index = NHWC linear index).
+    b_off: index of the first image of this tensor inside the engine's batch (chunked evaluation of a large batch)."""
     b, c, h, w = shape_nchw
-    idx = ((np.arange(b)[:, None, None, None] * h + np.arange(h)[None, None, :, None]) * w
+    idx = (((np.arange(b) + b_off)[:, None, None, None] * h + np.arange(h)[None, None, :, None]) * w
            + np.arange(w)[None, None, None, :]) * c + np.arange(c)[None, :, None, None]
     with np.errstate(over='ignore'):
         lseed = np.uint32((seed + (key + 1) * 0x632BE5AB) & 0xFFFFFFFF)
@@ -163,8 +164,9 @@ def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None, dropout=Non
     sd: reference-format state dict (OIHW conv weights); x: (B,Cin,H,W) fp32;
     time: (B,1) fp32 noise level (sr3) or (B,) int64 timestep (ddpm).
     taps: optional dict that receives every layer output (name -> tensor).
-    dropout: None (eval) or (p, seed): train-mode dropout with the engine's counter-based mask, keyed per
-    block by its FiLM row offset (cumulative Cout of the preceding blocks in downs, mid, ups order).
+    dropout: None (eval) or (p, seed[, b_off]): train-mode dropout with the engine's counter-based mask, keyed per
+    block by its FiLM row offset (cumulative Cout of the preceding blocks in downs, mid, ups order); b_off = position
+    of x[0] in the engine's batch when a large batch is evaluated in chunks.
     """
     variant = desc['variant']
     groups = desc['norm_groups']
@@ -191,7 +193,7 @@ def unet_forward(sd, desc, x, time, prefix='denoise_fn.', taps=None, dropout=Non
         if layer['kind'] == 'up':                                   # unet.py:58-65
             return F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'),
                             sd[n + '.conv.weight'], sd[n + '.conv.bias'], padding=1)
-        drop = None if dropout is None else (dropout[0], dropout[1], film_row[0])
+        drop = None if dropout is None else (dropout[0], dropout[1], film_row[0], dropout[2] if len(dropout) > 2 else 0)
         film_row[0] += layer['cout']
         x = resnet_block(sd, n + '.res_block', x, temb, groups, variant, drop)
         if layer['attn']:
@@ -296,9 +298,9 @@ def p_sample(sd, desc, tab, x, t, z, condition_x=None):
     """One reverse step with injected noise z.  sr3 diffusion.py:151-174 / ddpm :175-198."""
     b = x.shape[0]
     if desc['variant'] == 'sr3':
-        level = torch.FloatTensor([tab['sqrt_alphas_cumprod_prev'][t + 1]]).repeat(b, 1)
+        level = torch.FloatTensor([tab['sqrt_alphas_cumprod_prev'][t + 1]]).repeat(b, 1).to(x.device)
     else:
-        level = torch.full((b,), t, dtype=torch.long)
+        level = torch.full((b,), t, dtype=torch.long, device=x.device)
     inp = torch.cat([condition_x, x], dim=1) if condition_x is not None else x
     eps = unet_forward(sd, desc, inp, level)
     return p_sample_update(tab, x, eps, t, z)
@@ -341,13 +343,13 @@ def p_losses_sr3(sd, desc, hr, sr, gamma, z, conditional=True, dropout=None, los
     return (z - eps).abs().sum() if loss_type == 'l1' else ((z - eps) ** 2).sum()
 
 
-def p_losses_ddpm(sd, desc, tab, hr, sr, t, z, conditional=False, loss_type='l1'):
+def p_losses_ddpm(sd, desc, tab, hr, sr, t, z, conditional=False, loss_type='l1', dropout=None):
     """ddpm diffusion.py:259-294 with injected (t (B,) int64, z)."""
-    a = torch.from_numpy(tab['sqrt_alphas_cumprod'])[t].view(-1, 1, 1, 1)
-    s = torch.from_numpy(tab['sqrt_one_minus_alphas_cumprod'])[t].view(-1, 1, 1, 1)
+    a = torch.from_numpy(tab['sqrt_alphas_cumprod'])[t.cpu()].view(-1, 1, 1, 1).to(hr.device)
+    s = torch.from_numpy(tab['sqrt_one_minus_alphas_cumprod'])[t.cpu()].view(-1, 1, 1, 1).to(hr.device)
     x_noisy = a * hr + s * z
     inp = torch.cat([sr, x_noisy], dim=1) if conditional else x_noisy
-    eps = unet_forward(sd, desc, inp, t)
+    eps = unet_forward(sd, desc, inp, t, dropout=dropout)
     # set_loss (diffusion.py:84-90): nn.L1Loss(reduction='sum') | nn.MSELoss(reduction='sum')
     return (z - eps).abs().sum() if loss_type == 'l1' else ((z - eps) ** 2).sum()
 

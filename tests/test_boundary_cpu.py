@@ -1,0 +1,113 @@
+"""Drop-in boundary conformance, CPU only.  Both trees call their package `model`, so the reference's call
+surface is read in a subprocess (tests/sig_dump.py) and compared with the drop-in's: every reference parameter list must be
+an exact PREFIX of ours (name, kind, default) and anything we add must be keyword-only with a default -- so every call
+the reference's sr.py / infer.py / sample.py can make binds identically.  Skipped where the reference tree is absent
+(the GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT
+
+PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
+REF = os.environ.get('SR3_REFERENCE', '/root/reference')
+needs_ref = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, 'model', 'networks.py')),
+                               reason='reference tree not present')
+
+
+def _dump(root):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'sig_dump.py'), root], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+@needs_ref
+def test_public_signatures_match_reference():
+    ref, ours = _dump(REF), _dump(PKG)
+    problems = []
+
+    def check(name, a, b):
+        if b[:len(a)] != a:
+            problems.append('%s: reference %s vs drop-in %s' % (name, a, b[:len(a)]))
+        for extra in b[len(a):]:
+            if extra[1] != 'KEYWORD_ONLY' or extra[2] is None:
+                problems.append('%s: extension parameter %s must be keyword-only with a default' % (name, extra))
+    n = 0
+    for k, v in ref.items():
+        assert k in ours, k
+        if isinstance(v, dict):
+            for meth, s in v.items():
+                if meth not in ours[k]:
+                    problems.append('%s.%s missing from the drop-in' % (k, meth))
+                else:
+                    check(k + '.' + meth, s, ours[k][meth])
+                    n += 1
+        else:
+            check(k, v, ours[k])
+            n += 1
+    assert not problems, '\n'.join(problems)
+    assert n >= 60          # DDPM (17 methods), both GaussianDiffusion classes, both UNets, factories
+
+
+@needs_ref
+@pytest.mark.parametrize('init_type', ['normal', 'kaiming', 'orthogonal'])
+def test_init_weights_schemes_draw_the_reference_weights(init_type):
+    """model/networks.py:14-77: same seed => same weights as the reference's `init_weights(netG, init_type)`."""
+    code = ('import sys, logging; sys.path.insert(0, %r); logging.disable(50); import torch; import model.networks as N;'
+            'from helpers_opt import opt; torch.manual_seed(5); net = N.define_G(opt()); torch.manual_seed(9);'
+            'N.init_weights(net, init_type=%r, scale=0.3, std=0.05);'
+            'torch.save({k: v for k, v in net.state_dict().items() if k.startswith("denoise_fn.")}, sys.argv[1])')
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, 'helpers_opt.py'), 'w') as f:
+        f.write('import sys\nsys.path.insert(0, %r)\nfrom helpers import opt_for\n'
+                'def opt():\n    o = opt_for("sr3_tiny", phase="val", gpu=False)\n    return o\n' % os.path.join(ROOT, 'tests'))
+    outs = {}
+    for tag, root in (('ref', REF), ('ours', PKG)):
+        out = os.path.join(tmp, tag + '.pth')
+        env = dict(os.environ, PYTHONPATH=tmp)
+        r = subprocess.run([sys.executable, '-c', code % (root, init_type), out], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-800:]
+        outs[tag] = torch.load(out)
+    assert set(outs['ref']) == set(outs['ours'])
+    for k, v in outs['ref'].items():
+        assert torch.equal(v, outs['ours'][k]), k
+
+
+def test_finetune_norm_raises_like_the_reference():
+    """model/model.py:26-40: no parameter name contains 'transformer' => Adam gets an empty list => ValueError."""
+    sys.path.insert(0, PKG)
+    import model as Model
+    from helpers import opt_for
+    opt = opt_for('sr3_tiny', phase='train', gpu=False)
+    opt['model']['finetune_norm'] = True
+    with pytest.raises(ValueError, match='empty parameter list'):
+        Model.create_model(opt)
+
+
+@needs_ref
+def test_reference_cpu_baseline_tool_runs(tmp_path):
+    """tools/ref_baseline.py (bench.py's cpu_baseline leg, kind "reference"): imports the reference in its own process,
+    loads the drop-in's weights by state-dict key, times p_sample and optimize_parameters."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, ROOT)
+    import bench
+    import model.networks as networks
+    opt = bench.config_opt('ddpm_128')
+    opt['gpu_ids'] = None
+    torch.manual_seed(0)
+    netG = networks.define_G(opt)
+    state = str(tmp_path / 'state.pth')
+    torch.save({'sd': dict(netG.state_dict()), 'x': torch.randn(1, 3, 128, 128), 'cond': None, 't': 1007}, state)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'ref_baseline.py'), '--ref', REF, '--config', 'ddpm_128',
+                        '--state', state, '--threads', '4', '--budget', '2', '--max-steps', '1', '--train-steps', '1',
+                        '--train-batch', '1'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-800:]
+    rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert rec['kind'] == 'reference' and rec['value'] > 0 and rec['train']['value'] > 0, rec

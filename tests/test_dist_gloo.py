@@ -109,3 +109,58 @@ def test_bucketed_gradient_allreduce_two_ranks():
         g, l = ret[r]
         assert torch.allclose(g, expect, atol=1e-6)
         assert l == 3.0
+
+
+class _IndexDataset(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {'Index': i}
+
+
+def _loader_worker(rank, world, port, n, bs, ret):
+    sys.path.insert(0, PKG)
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import data as Data
+    from sr3_hip.dist import dp_world_size
+    dl = Data.create_dataloader(_IndexDataset(n), dict(batch_size=bs, use_shuffle=True, num_workers=0), 'train')
+    epochs = []
+    for _ in range(2):
+        seen, sizes = [], []
+        for batch in dl:
+            seen += batch['Index'].tolist()
+            sizes.append(len(batch['Index']))
+        epochs.append((seen, sizes))
+    ret[rank] = (epochs, dp_world_size(), dl.batch_size)
+    dist.destroy_process_group()
+
+
+def test_rank_sharded_training_loader_two_ranks():
+    """create_dataloader under torch.distributed: `batch_size` stays the global batch (DataParallel semantics), each rank
+    draws batch_size / world samples from a disjoint shard, shards reshuffle together every epoch."""
+    world, n, bs = 2, 24, 8
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_loader_worker, args=(world, port, n, bs, ret), nprocs=world, join=True)
+    for e in range(2):
+        a, b = ret[0][0][e][0], ret[1][0][e][0]
+        assert not (set(a) & set(b)) and sorted(a + b) == list(range(n))
+        assert all(s == bs // world for s in ret[0][0][e][1])
+    assert ret[0][0][0][0] != ret[0][0][1][0]              # set_epoch: a new permutation each pass
+    assert ret[0][1] == ret[1][1] == 2 and ret[0][2] == bs // world
+    # an indivisible global batch is refused rather than silently changed
+    sys.path.insert(0, PKG)
+
+
+def test_single_process_loader_unchanged():
+    sys.path.insert(0, PKG)
+    import data as Data
+    dl = Data.create_dataloader(_IndexDataset(10), dict(batch_size=4, use_shuffle=False, num_workers=0), 'train')
+    assert [b['Index'].tolist() for b in dl] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]

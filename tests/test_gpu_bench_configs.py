@@ -1,0 +1,178 @@
+"""Parity at the configurations bench.py actually times (BASELINE.json configs, at THEIR batch sizes), against the
+CPU oracle on the same seeded inputs:
+
+  C2  SR3 16->128, batch 16: UNet forward with per-sample noise levels, and ONE hipGraph-replayed reverse step -- the
+      very graph `bench.py` replays 2000 times (in-graph z draw, device step counter, fused update);
+  C4  SR3 64->512, batch 4: one graph-replayed reverse step;
+  C5  DDPM-128, batch 32: UNet forward with per-sample timesteps; training step with dropout 0.2;
+  C3  SR3 16->128 training, batch 64, dropout 0.2 (the `train` leg of bench.py): loss and every parameter gradient
+      vs torch autograd over the oracle, evaluated in 8 chunks of 8 images (the gradient of the sum-reduced loss is
+      the sum over chunks; the dropout mask is a function of the element's index in the full batch).
+
+The plans at these batch sizes pick other tiles than at batch 1 (8-wave 256x128 tile, split-K 2/4/8/16 on the small
+layers, the 8-wave 64x32 dropout form) -- each test asserts the plan really contains them, so a heuristic change
+that silently moves the bench onto untested kernels fails here.
+Tolerances: forward / step 2e-5 * max(1, |ref|_inf); loss rel 1e-5; gradients normwise rel 1e-4."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gpu_util as G                                # noqa: E402
+from test_gpu_fullsize import CONFIGS, make_opt     # noqa: E402
+
+
+def _build(name, phase='val', seed=11, dropout=0.0):
+    from oracle import sr3_oracle as O
+    import model.networks as networks
+    c = CONFIGS[name]
+    opt = make_opt(c)
+    opt['phase'] = phase
+    opt['model']['unet']['dropout'] = dropout
+    torch.manual_seed(seed)
+    netG = networks.define_G(opt)        # 'val': PyTorch default init, 'train': orthogonal -- reference draw order
+    sd = {k: v.clone() for k, v in netG.state_dict().items()}
+    d = G.dev()
+    netG = netG.to(d)
+    netG.set_loss(d)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule'][phase], d)
+    netG.show_progress = False
+    return netG, sd, O.desc_from_opt(opt), opt, c
+
+
+def _cfgs(netG, B):
+    return [(o['tile_cfg'], o['ksplit']) for o in netG.denoise_fn.plan.op_list(B) if o['kind'] == 50]
+
+
+def _graph_step_vs_oracle(netG, sd, desc, opt, c, B, t, what):
+    """Replay the production one-step graph once from (x, cond, step = t); the graph draws z itself, so read it back
+    and hand the same z to the oracle's p_sample."""
+    from oracle import sr3_oracle as O
+    d = G.dev()
+    S = c['size']
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, S, S, generator=g)
+    cond = (torch.rand(B, 3, S, S, generator=g) * 2 - 1) if c['cond'] else None
+    shape = (B, 3, S, S)
+    st = netG._loop_state(shape, shape if c['cond'] else None, d)
+    netG._capture(st)
+    st['img'].copy_(x)
+    if cond is not None:
+        st['cond'].copy_(cond)
+    st['step'].fill_(t)
+    st['graph'].replay()
+    torch.cuda.synchronize()
+    assert int(st['step'].item()) == t - 1
+    z = st['z'].cpu()
+    got_eps, got_x = st['eps'].cpu(), st['img'].cpu()
+    tab = O.schedule_tables(opt['model']['beta_schedule']['val'])
+    with torch.no_grad():
+        inp = x if cond is None else torch.cat([cond, x], 1)
+        if c['which'] == 'sr3':
+            lvl = torch.full((B, 1), float(tab['sqrt_alphas_cumprod_prev'][t + 1]), dtype=torch.float32)
+            ref_eps = O.unet_forward(sd, desc, inp, lvl)
+        else:
+            ref_eps = O.unet_forward(sd, desc, inp, torch.full((B,), t, dtype=torch.long))
+        ref_x = O.p_sample_update(tab, x, ref_eps, t, z)
+    e1 = G.assert_close(got_eps, ref_eps, what=what + ' eps (graph replay)')
+    e2 = G.assert_close(got_x, ref_x, what=what + ' x_{t-1} (graph replay)')
+    print('%s: graph-replayed reverse step at batch %d: eps max abs err %.2e, x max abs err %.2e (|eps|max %.2f)'
+          % (what, B, e1, e2, ref_eps.abs().max().item()))
+
+
+def test_c2_batch16_forward_and_graph_step():
+    from oracle import sr3_oracle as O
+    B = 16
+    netG, sd, desc, opt, c = _build('sr3_16_128')
+    cfgs = _cfgs(netG, B)
+    # the bench plan: 8-wave 256x128 tile, 256x64 tile, 128x128 tile with split-K up to 16
+    assert (9, 1) in cfgs and (6, 1) in cfgs and any(t == 5 and k >= 8 for t, k in cfgs), sorted(set(cfgs))
+    d = G.dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 6, 128, 128, generator=g)
+    lvl = torch.linspace(0.05, 0.999, B).view(B, 1)           # a different noise level per sample
+    with torch.no_grad():
+        ref = O.unet_forward(sd, desc, x, lvl)
+    got = netG.denoise_fn(x.to(d), lvl.to(d)).cpu()
+    err = G.assert_close(got, ref, what='C2 batch 16 eps')
+    print('C2 batch 16: eps max abs err %.2e (|ref|max %.2f)' % (err, ref.abs().max().item()))
+    _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2')
+
+
+def test_c4_batch4_graph_step():
+    B = 4
+    netG, sd, desc, opt, c = _build('sr3_64_512')
+    cfgs = _cfgs(netG, B)
+    assert any(t == 9 for t, _ in cfgs) and any(t == 6 for t, _ in cfgs), sorted(set(cfgs))
+    _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 777, 'C4')
+
+
+def test_c5_batch32_forward():
+    from oracle import sr3_oracle as O
+    B = 32
+    netG, sd, desc, opt, c = _build('ddpm_128')
+    d = G.dev()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 3, 128, 128, generator=g)
+    t = torch.randint(0, 2000, (B,), generator=g)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, desc, x, t)
+    got = netG.denoise_fn(x.to(d), t.to(d)).cpu()
+    err = G.assert_close(got, ref, what='C5 batch 32 eps')
+    print('C5 batch 32: eps max abs err %.2e (|ref|max %.2f)' % (err, ref.abs().max().item()))
+
+
+def _train_step_vs_chunked_oracle(name, B, chunk, p_drop, seed):
+    from oracle import sr3_oracle as O
+    netG, sd, desc, opt, c = _build(name, phase='train', seed=17, dropout=p_drop)
+    netG.train()
+    d = G.dev()
+    S = c['size']
+    g = torch.Generator().manual_seed(8)
+    hr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    sr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    z = torch.randn(B, 3, S, S, generator=g)
+    data = {'HR': hr.to(d), 'SR': sr.to(d)}
+    if c['which'] == 'sr3':
+        gamma = torch.rand(B, generator=g) * 0.9 + 0.05
+        loss = netG.p_losses(data, noise=z.to(d), gamma=gamma, drop_seed=seed)
+    else:
+        t = torch.randint(0, 2000, (B,), generator=g)
+        tab = O.schedule_tables(opt['model']['beta_schedule']['train'])
+        loss = netG.p_losses(data, noise=z.to(d), t=t.to(d), drop_seed=seed)
+    torch.cuda.synchronize()
+    got_loss = float(loss)
+    grads = {k: v.cpu().clone() for k, v in netG.denoise_fn.named_gradients()}
+    # dropout convs of the train plan: none may sit on a tile without a tested dropout instantiation
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
+    ref_loss = 0.0
+    for lo in range(0, B, chunk):
+        sl = slice(lo, lo + chunk)
+        drop = (p_drop, seed, lo) if p_drop > 0 else None
+        if c['which'] == 'sr3':
+            l = O.p_losses_sr3(sdr, desc, hr[sl], sr[sl], gamma[sl], z[sl], conditional=True, dropout=drop)
+        else:
+            l = O.p_losses_ddpm(sdr, desc, tab, hr[sl], sr[sl], t[sl], z[sl], conditional=False, dropout=drop)
+        (l / hr.numel()).backward()              # 1 / (GLOBAL b c h w), model/model.py:52-53
+        ref_loss += float(l.detach())
+    assert abs(got_loss - ref_loss) <= 1e-5 * abs(ref_loss), (got_loss, ref_loss)
+    worst = []
+    for key, grad in grads.items():
+        ref = sdr['denoise_fn.' + key].grad
+        num, den = (grad - ref).norm().item(), max(ref.norm().item(), 1e-12)
+        worst.append((num / den, key, den))
+    worst.sort(reverse=True)
+    bad = [w for w in worst if w[0] > 1e-4 and w[2] > 1e-7]
+    assert len(worst) > 150 and not bad, bad[:8]
+    print('%s training step, batch %d, dropout %.1f: loss rel err %.1e, worst gradient rel err %.1e (%s) over %d tensors'
+          % (name, B, p_drop, abs(got_loss - ref_loss) / abs(ref_loss), worst[0][0], worst[0][1], len(worst)))
+
+
+def test_c3_train_batch64_dropout():
+    """The `train` leg of bench.py: SR3 16->128, 64 images per GPU, dropout 0.2."""
+    _train_step_vs_chunked_oracle('sr3_16_128', 64, 8, 0.2, 20240607)
+
+
+def test_c5_train_batch32_dropout():
+    """BASELINE.json configs[4]: DDPM-128 training, 32 images per GPU, dropout 0.2 (config/sample_ddpm_128.json)."""
+    _train_step_vs_chunked_oracle('ddpm_128', 32, 8, 0.2, 77001)

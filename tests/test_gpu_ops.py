@@ -18,6 +18,71 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+DROP_CASES = [
+    # name, B, C0, H, W, Cout, X0, X1 (fused res_conv sources, 0 = none), residual, tile_cfg, ksplit
+    ('cfg5_16x16', 2, 64, 16, 16, 128, 0, 0, True, 5, 1),
+    ('cfg5_x2', 2, 128, 16, 16, 128, 96, 32, False, 5, 1),
+    ('cfg5_splitk', 3, 128, 8, 8, 128, 0, 0, True, 5, 2),
+    ('cfg6_8wave_64x32', 2, 64, 32, 16, 64, 0, 0, True, 6, 1),
+    ('cfg6_8wave_x2', 1, 64, 32, 32, 64, 64, 32, False, 6, 1),
+    ('im2col_small', 3, 32, 4, 4, 32, 0, 0, True, 3, 1),
+    ('auto', 2, 64, 16, 16, 64, 0, 0, True, 0, 0),
+    # the geometries of the B = 64 training plan bench.py times (C3): 128^2 layers on the 8-wave 64x32 form of the
+    # 256x64 tile, 64^2 layers on the 128x128 tile (the plan swaps the 8-wave 256x128 tile out for dropout convs)
+    ('c3_128sq_64to64_x2_192', 1, 64, 128, 128, 64, 128, 64, False, 6, 1),
+    ('c3_64sq_128to128_x2_256', 1, 128, 64, 64, 128, 128, 128, False, 5, 1),
+]
+
+
+@pytest.mark.parametrize('case', DROP_CASES, ids=[c[0] for c in DROP_CASES])
+def test_conv_dropout(case):
+    """Train-mode Block: conv3x3(dropout(silu(gn(x)))) (+ fused res_conv) through sr3_conv_dropout_f32 vs a float64
+    reference that applies the same counter-based mask (oracle.sr3_oracle.hash32 restates the engine's hash)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from oracle import sr3_oracle as O
+    name, B, C0, H, W, Cout, X0, X1, use_res, tile_cfg, ksplit = case
+    lib = L.load()
+    d = G.dev()
+    p_drop, seed = 0.2, 0x1234ABCD
+    cc = ('drop', B, C0, 0, H, W, Cout, 3, 1, 0, 2, True, use_res, True)
+    src0, _, w, kw = _make_case(cc, seed=31)
+    # float64 reference with the engine's mask (NHWC linear index of the activated input)
+    x = src0.double() * kw['ss'][:, :, 0].double()[:, :, None, None] + kw['ss'][:, :, 1].double()[:, :, None, None]
+    x = x * torch.sigmoid(x)
+    idx = ((np.arange(B)[:, None, None, None] * H + np.arange(H)[None, None, :, None]) * W
+           + np.arange(W)[None, None, None, :]) * C0 + np.arange(C0)[None, :, None, None]
+    with np.errstate(over='ignore'):
+        hv = O.hash32(idx.astype(np.uint32) * np.uint32(0x9E3779B9) + np.uint32(seed))
+    keep = torch.from_numpy((hv >= np.uint32(int(p_drop * 4294967296.0))).astype(np.float64))
+    assert 0.75 < keep.mean().item() < 0.85
+    x = x * keep * float(np.float32(1.0 / (1.0 - p_drop)))
+    ref = F.conv2d(x, w.double(), kw['bias'].double(), padding=1) + kw['film'].double()[:, :, None, None]
+    if use_res:
+        ref = ref + kw['res0'].double()
+    g = lambda t: None if t is None else t.to(d)
+    x2a = x2b = w2 = b2 = None
+    if X0:
+        x2a = _rand(B, X0, H, W, seed=41)
+        x2b = _rand(B, X1, H, W, seed=42) if X1 else None
+        w2 = _rand(Cout, X0 + X1, 1, 1, seed=43) * 0.1
+        b2 = _rand(Cout, seed=44)
+        ref = ref + F.conv2d((x2a if x2b is None else torch.cat([x2a, x2b], 1)).double(), w2.double(), b2.double())
+    dv = dict(s0=g(G.nhwc(src0)), w=g(G.ohwi(w)), bias=g(kw['bias']), ss=g(kw['ss']), film=g(kw['film']),
+              res=g(G.nhwc(kw['res0'])) if use_res else None,
+              x2a=None if x2a is None else g(G.nhwc(x2a)), x2b=None if x2b is None else g(G.nhwc(x2b)),
+              w2=None if w2 is None else g(w2.reshape(Cout, -1).contiguous()), b2=g(b2))
+    out = torch.full((B, H, W, Cout), float('nan'), device=d)
+    nb = int(lib.sr3_conv_scratch_bytes(B, H, W, C0, Cout, 3, tile_cfg, ksplit))
+    scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
+    L.check(lib.sr3_conv_dropout_f32(L.ptr(dv['s0']), C0, B, H, W, Cout, L.ptr(dv['w']), L.ptr(dv['bias']), L.ptr(dv['ss']),
+                                     2, L.ptr(dv['film']), Cout, L.ptr(dv['res']), Cout, L.ptr(dv['x2a']), X0,
+                                     L.ptr(dv['x2b']), X1, L.ptr(dv['w2']), L.ptr(dv['b2']), L.ptr(out), None, tile_cfg,
+                                     ksplit, L.ptr(scratch), nb, seed, p_drop, G.stream()))
+    torch.cuda.synchronize()
+    G.assert_close(G.nchw(out).cpu(), ref, what='dropout conv ' + name)
+
+
 CONV_CASES = [
     # name, B, C0, C1, H, W, Cout, k, stride, ups, act, film, res, bias
     ('plain3x3', 2, 64, 0, 16, 16, 64, 3, 1, 0, 0, False, False, True),
