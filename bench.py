@@ -331,7 +331,8 @@ def roofline_from_profile(netG, x, cond, reps=3):
              255: 'k_conv3x3_halo<4,2,false,false,0,2>', 257: 'k_conv3x3_halo<4,2,true,false,0,2>',
              155: 'k_conv3x3_halo<2,2,false,false,1,2>', 157: 'k_conv3x3_halo<2,2,true,false,1,2>',
              156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
-             355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>'}
+             355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
+             455: 'k_conv3x3_wino<1>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -343,7 +344,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
               for k, v in sorted(agg.items())}
     traffic = None
     counters = None
-    kname = 'sr3::' + names[dom].replace(',', ', ')
+    kname = 'void sr3::' + names[dom].replace(',', ', ') if dom == 455 else 'sr3::' + names[dom].replace(',', ', ')
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
         with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_hbm_traffic.json')) as f:
             traffic = json.load(f)[kname]['hbm_bytes_per_launch']
@@ -355,12 +356,22 @@ def roofline_from_profile(netG, x, cond, reps=3):
         counters = {'dominant_kernel': sq.get(kname), 'attention': sq.get('attention')}
     except (OSError, ValueError):
         pass
-    is_split = names[dom].split(',')[4] == '1'
+    is_wino = dom == 455
+    is_split = (not is_wino) and names[dom].split(',')[4] == '1'
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
+    extra = {}
+    if is_wino:
+        # Winograd F(2x2,3x3): 16 multiplies per 2x2 output block and (cin, cout) pair instead of 36.  `achieved` stays
+        # the ALGORITHMIC (direct-convolution) FLOP rate SURVEY.md 8d defines, so it may exceed the MFMA peak; the MFMA
+        # pipe itself executes 1/2.25 of those FLOPs: `executed_*` is the fraction of the fp32 MFMA roof the kernel runs at.
+        extra = dict(executed_mfma_tflops=achieved / 2.25, executed_frac=achieved / 2.25 / peak,
+                     note='Winograd F(2x2,3x3): frac = algorithmic (direct-conv) FLOP/s / fp32 MFMA peak, can exceed 1; '
+                          'executed_frac = MFMA FLOPs actually issued (algorithmic / 2.25) / peak')
     return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
-                                                   else ' (v_mfma_f32_32x32x2_f32)'), achieved=achieved,
-                peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic,
+                                                   else (' (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)' if is_wino
+                                                         else ' (v_mfma_f32_32x32x2_f32)')), achieved=achieved,
+                peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic, **extra,
                 traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/%s_bench_hbm_pmc.csv'
                              % PROFILE_ROUND,
                 avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,

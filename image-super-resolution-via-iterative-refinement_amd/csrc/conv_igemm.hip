@@ -347,6 +347,24 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       if ((long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn) >= 448) { tile_cfg = order[k]; break; }
     }
   }
+  if (ksplit == 0 && tile_cfg == 11) {
+    // Winograd kernel: one 8-wave workgroup per CU, so one full round of 256 is the target; a split keeps >= 4 chunks
+    // (64 input channels)
+    WinoGeom wg;
+    if (!wino_geometry(p, &wg)) { ksplit = 1; return; }
+    const long tiles = wino_workgroups(p, wg);
+    const int units = wino_chunks(p);
+    int ks = 1;
+    if (tiles < 256) {
+      ks = (int)((256 + tiles - 1) / tiles);
+      const int cap = units / 4 > 1 ? units / 4 : 1;
+      if (ks > cap) ks = cap;
+      if (ks > 16) ks = 16;
+    }
+    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;
+    ksplit = ks;
+    return;
+  }
   if (ksplit == 0) {
     long tiles;
     int units, min_units;
@@ -434,9 +452,11 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   int rc;
   const bool k3 = p.ksize == 3;
-  if (p.x2_w && (tile_cfg < 5 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
+  if (p.x2_w && (tile_cfg < 5 || tile_cfg == 11 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
   if (p.x2_w && ((p.x2_C0 & 3) || (p.x2_C1 & 3) || !p.x2_src0 || (p.x2_C1 > 0 && !p.x2_src1))) { set_error("conv: bad x2 segment"); return SR3_E_BADARG; }
-  if (tile_cfg >= 5) {
+  if (tile_cfg == 11) {
+    rc = conv3x3_wino_forward(p, p.wino_u, st);
+  } else if (tile_cfg >= 5) {
     HaloGeom g;
     if (tile_cfg > 10 || !halo_geometry(p, tile_cfg, &g)) { set_error("conv: halo tile_cfg %d does not fit this problem", tile_cfg); return SR3_E_UNSUPPORTED; }
     const int nchunks = cdiv(Cin, 32);

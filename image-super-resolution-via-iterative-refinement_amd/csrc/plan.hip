@@ -226,6 +226,22 @@ static int build_structure(sr3_plan* P) {
   P->fin_w = add_conv(P, "final_conv.block.3.weight", out_ch, P->fin_cin, 3, &cur);
   P->fin_b = add_vec(P, "final_conv.block.3.bias", out_ch, &cur);
   P->param_floats = (cur + 3) & ~(size_t)3;
+  // derived (Winograd) filters of every 3x3 stride-1 conv: the two convs of each ResnetBlock and the Upsample convs
+  {
+    size_t dcur = 0;
+    auto reg = [&](size_t w, int Cout, int Cin) {
+      if (Cin & 3) return;
+      P->derived.push_back({w, Cout, Cin, dcur});
+      P->derived_of[w] = dcur;
+      dcur += wino_weight_floats(Cout, Cin);
+    };
+    for (auto* v : {&P->downs, &P->mid, &P->ups})
+      for (auto& L : *v) {
+        if (L.kind == 1) { reg(L.res.c1_w, L.res.cout, L.res.cin); reg(L.res.c2_w, L.res.cout, L.res.cout); }
+        else if (L.kind == 3) reg(L.w, L.cout, L.cin);
+      }
+    P->derived_floats = dcur;
+  }
 
   // every GroupNorm must divide
   auto chk = [&](int c) { return c % d.norm_groups == 0; };
@@ -345,6 +361,14 @@ struct Builder {
     ops.push_back(o);
     max_cin = std::max(max_cin, Cf);
   }
+  // inference plans run every 3x3 stride-1 conv the Winograd kernel covers on it (plan option `winograd`, default on;
+  // an explicit tile_cfg / split_bf16 / the training plan keep the direct halo kernels)
+  bool wino_ok(const ConvParams& c, size_t w, bool has_x2, bool has_drop) {
+    if (!P->winograd || train || P->tile_cfg != 0 || P->split_bf16 || has_x2 || has_drop) return false;
+    if (c.ksize != 3 || c.stride != 1 || !P->derived_of.count(w)) return false;
+    WinoGeom wg;
+    return wino_geometry(c, &wg);
+  }
   // generic conv over the virtual concat (x0|x1); residual is the concat view (r0|r1)
   int conv(int x0, int x1, int Cout, int ksize, int stride, int ups, int act_mode, size_t w, bool has_bias,
            size_t bias, int film_row, int r0, int r1, bool want_stats, int q0 = -1, int q1 = -1, size_t qw = 0,
@@ -377,6 +401,10 @@ struct Builder {
       HaloGeom sg;
       if (P->split_bf16 && !train && o.tile_cfg == 0 && ksize == 3 && stride == 1 && Cout > 64 && halo_geometry(c, 10, &sg))
         o.tile_cfg = 10;
+    }
+    if (wino_ok(c, w, q0 >= 0, o.has_drop)) {
+      o.tile_cfg = 11;
+      o.wino_off = P->derived_of[w];
     }
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
@@ -421,7 +449,12 @@ struct Builder {
     }
     if (o.ksplit > 1) max_scratch = std::max(max_scratch, (size_t)o.ksplit * B * Ho * Wo * Cout * sizeof(float));
     // split-K convs leave the statistics to the (cheap, small-tensor) stand-alone pass
-    if (want_stats && P->fuse_stats && o.ksplit == 1 && o.tile_cfg >= 5) {
+    if (want_stats && P->fuse_stats && o.ksplit == 1 && o.tile_cfg == 11) {
+      WinoGeom wg;
+      wino_geometry(c, &wg);
+      stat_slot(out, wino_stats_slices(wg));
+      o.has_ostat = true; o.f = T[out].stat_off;
+    } else if (want_stats && P->fuse_stats && o.ksplit == 1 && o.tile_cfg >= 5) {
       HaloGeom hg;
       if (halo_geometry(c, o.tile_cfg, &hg)) {
         stat_slot(out, halo_stats_slices(hg));
@@ -439,12 +472,14 @@ struct Builder {
     return out;
   }
   // can block2's conv run on the halo kernel (which can take res_conv as a second K-segment)?
-  bool can_fuse_x2(int h1, int Cout) {
+  bool can_fuse_x2(int h1, int Cout, size_t w) {
     if (!P->fuse_res) return false;
     ConvParams c;
     memset(&c, 0, sizeof(c));
     c.C0 = T[h1].C; c.B = B; c.Hs = T[h1].H; c.Ws = T[h1].W; c.stride = 1; c.ksize = 3;
     c.Ho = T[h1].H; c.Wo = T[h1].W; c.Cout = Cout;
+    // the Winograd kernel has no second K-segment: res_conv runs as its own 1x1 GEMM and joins as a residual
+    if (wino_ok(c, w, false, false)) return false;
     int cfg = P->tile_cfg, ks = P->ksplit;
     conv_pick(c, cfg, ks);
     return cfg >= 5;
@@ -454,7 +489,7 @@ struct Builder {
     const int h1 = conv(x0, x1, R.cout, 3, 1, 0, 2, R.c1_w, true, R.c1_b, R.film_off, -1, -1, true);
     fold(h1, -1, R.gn2_w, R.gn2_b);
     int out;
-    if (R.has_rc && can_fuse_x2(h1, R.cout)) {
+    if (R.has_rc && can_fuse_x2(h1, R.cout, R.c2_w)) {
       out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, -1, -1, true, x0, x1, R.rc_w, R.rc_b, R.film_off);
     } else if (R.has_rc) {
       const int r = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
@@ -655,6 +690,10 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
           c.x2_w = params + o.p2;
           c.x2_bias = params + o.p3;
         }
+        if (o.tile_cfg == 11) {
+          if (!P->derived_ptr) { set_error("the plan's derived (Winograd) weights are not bound: call sr3_plan_bind_derived + sr3_plan_prepare_derived"); return SR3_E_BADARG; }
+          c.wino_u = P->derived_ptr + o.wino_off;
+        }
         if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
         rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + R.scratch_off), R.scratch_bytes, st);
         break;
@@ -764,7 +803,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
   P->t_wt_off = off; off += al(max_wt);
   P->t_slab_off = off; off += al(max_slab);
   P->t_part_off = off; off += al(max_part);
-  P->t_gs_off = off; off += al((size_t)B * G * 2 * sizeof(float));
+  P->t_gs_off = off; off += al((size_t)B * G * 2 * sizeof(double));
   P->t_dfilm_off = off; off += al((size_t)B * P->F * sizeof(float));
   P->t_xnoisy_off = off; off += al((size_t)B * (d.in_channel - cond_channels) * S * S * sizeof(float));
   P->t_eps_off = off; off += al((size_t)B * P->out_ch * S * S * sizeof(float));
@@ -883,6 +922,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "keep_all")) slot = &plan->keep_all;
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
+  else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
@@ -900,6 +940,27 @@ int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_
   if (C) *C = t.C;
   if (H) *H = t.H;
   if (W) *W = t.W;
+  return SR3_OK;
+}
+
+size_t sr3_plan_derived_bytes(const sr3_plan* plan) { return plan ? plan->derived_floats * sizeof(float) : 0; }
+int sr3_plan_bind_derived(sr3_plan* plan, void* buffer, size_t bytes) {
+  if (!plan) { set_error("null plan"); return SR3_E_BADARG; }
+  if (buffer && (bytes < plan->derived_floats * sizeof(float) || ((uintptr_t)buffer & 15))) {
+    set_error("derived buffer too small or misaligned (%zu < %zu)", bytes, plan->derived_floats * sizeof(float));
+    return SR3_E_NOMEM;
+  }
+  plan->derived_ptr = static_cast<float*>(buffer);
+  plan->derived_bound_bytes = buffer ? bytes : 0;
+  return SR3_OK;
+}
+int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) {
+  if (!plan || !params) { set_error("null argument"); return SR3_E_BADARG; }
+  if (!plan->derived_ptr) { set_error("no derived buffer bound"); return SR3_E_BADARG; }
+  for (const auto& d : plan->derived) {
+    const int rc = wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
   return SR3_OK;
 }
 
@@ -964,9 +1025,9 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
       if (o.kind == OP_CONV) {
         // 51-54 im2col kernel tile configs; 55/56 halo-tile 3x3 kernel (57/58: with the fused 1x1 segment)
         //        155-158: the same four on the opt-in split-bf16 instantiations; 255/257: the 8-wave 256x128 tile
-        //        (cfg 9), 355/357: its split-bf16 twin (cfg 10)
+        //        (cfg 9), 355/357: its split-bf16 twin (cfg 10); 455: the Winograd F(2x2,3x3) kernel (cfg 11)
         {
-          static const int base[11] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305};
+          static const int base[12] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305, 405};
           kind += base[o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
         }
         const ConvParams& c = o.cp;
@@ -1021,6 +1082,19 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
   c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
+  if (tile_cfg == 11 && (ksize != 3 || stride != 1)) { set_error("conv: the Winograd kernel does not fit this problem (3x3 stride 1 only)"); return SR3_E_UNSUPPORTED; }
+  if (tile_cfg == 11) {
+    // Winograd form through the per-op entry: the transformed filters are derived here, behind the split-K slabs in
+    // `scratch` (sr3_conv_scratch_bytes accounts for them); a plan keeps them in its derived buffer instead.
+    const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
+    const size_t ub = wino_weight_floats(Cout, c.C0 + c.C1) * sizeof(float);
+    if (!scratch || scratch_bytes < slab + ub || ksize != 3) { set_error("conv: Winograd scratch too small (%zu < %zu)", scratch_bytes, slab + ub); return SR3_E_NOMEM; }
+    float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
+    const int rc = wino_transform_weights(w, Cout, c.C0 + c.C1, u, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    c.wino_u = u;
+    scratch_bytes = slab;
+  }
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
 }
 int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int H, int W, int Cout,
@@ -1058,15 +1132,21 @@ int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cou
   }
   // same mapping p -> (threshold, scale) as sr3_train_step
   c.drop_seed = drop_seed;
-  c.drop_thresh = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
-  c.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  dropout_consts(drop_p, &c.drop_thresh, &c.drop_scale);
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
+}
+unsigned sr3_dropout_threshold(float drop_p, float* scale_out) {
+  unsigned t = 0;
+  float s = 1.f;
+  if (drop_p > 0.f && drop_p < 1.f) dropout_consts(drop_p, &t, &s);
+  if (scale_out) *scale_out = s;
+  return t;
 }
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit) {
   ConvParams c;
   memset(&c, 0, sizeof(c));
-  c.B = B; c.Ho = Ho; c.Wo = Wo; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
-  return conv_splitk_bytes(c, tile_cfg, ksplit);
+  c.B = B; c.Ho = Ho; c.Wo = Wo; c.Hs = Ho; c.Ws = Wo; c.stride = 1; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
+  return conv_splitk_bytes(c, tile_cfg, ksplit) + (tile_cfg == 11 ? wino_weight_floats(Cout, Cin) * sizeof(float) : 0);
 }
 int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, void* stream) {
   if (!x || !stat) { set_error("null argument"); return SR3_E_BADARG; }
@@ -1082,6 +1162,10 @@ int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int
   if (ksplit > 1) {
     const int rpb = splitk_rows_per_block(c, true);
     return rpb > 0 ? (c.Ho * c.Wo) / rpb : 0;
+  }
+  if (tile_cfg == 11) {
+    WinoGeom wg;
+    return wino_geometry(c, &wg) ? wino_stats_slices(wg) : 0;
   }
   HaloGeom g;
   if (tile_cfg < 5 || !halo_geometry(c, tile_cfg, &g)) return 0;

@@ -56,6 +56,7 @@ struct Op {
   unsigned drop_key = 0;
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
+  size_t wino_off = 0;             // tile_cfg 11: float offset of this conv's transformed filters in the derived buffer
 };
 
 struct Tap { std::string name; size_t off; int C, H, W; };
@@ -100,6 +101,14 @@ struct sr3_plan {
   int fin_cin = 0, out_ch = 0;
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
+  int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
+  // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
+  struct Derived { size_t w; int Cout, Cin; size_t off; };
+  std::vector<Derived> derived;
+  std::map<size_t, size_t> derived_of;     // weight arena offset -> float offset in the derived buffer
+  size_t derived_floats = 0;
+  float* derived_ptr = nullptr;
+  size_t derived_bound_bytes = 0;
   int loss_l2 = 0;           // training loss: 0 = L1 (sum), 1 = L2 (sum)  (set_loss, diffusion.py:84-90)
   // compiled forward
   int built_batch = -1;

@@ -41,6 +41,18 @@ inline int ensure_max_lds(const void* kern, int bytes, std::atomic<uint64_t>& do
   return SR3_OK;
 }
 
+// The C ABI carries fp32 hyper-parameters (lr, betas, dropout p) while the reference evaluates expressions of them as
+// Python floats (double): recover the decimal the caller meant (0.2f -> 0.2, 1e-4f -> 1e-4) = the shortest decimal
+// that rounds back to the same float, so derived quantities (Adam bias corrections, the dropout threshold p * 2^32)
+// match the reference's double arithmetic exactly.
+double meant_double(float f);
+// dropout p -> (keep threshold on the 32-bit hash, 1 / (1 - p)); one definition for every entry point and the oracle
+inline void dropout_consts(float p, unsigned* thresh, float* scale) {
+  const double pd = meant_double(p);
+  *thresh = p > 0.f ? (unsigned)(pd * 4294967296.0) : 0u;
+  *scale = p > 0.f ? (float)(1.0 / (1.0 - pd)) : 1.0f;
+}
+
 // ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
 // Activations are NHWC fp32.  The input is the *virtual* channel concat of up to two sources,
 // optionally nearest-upsampled x2 (gather in the address math), optionally strided.
@@ -85,6 +97,8 @@ struct ConvParams {
   // single-source, non-upsampled inputs (block2's input is never a concat).
   unsigned drop_seed, drop_thresh;
   float drop_scale;
+  // tile_cfg 11 (Winograd): the transformed filters of this conv in fragment-major order (conv3x3_wino.hip)
+  const float* wino_u;
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -121,6 +135,24 @@ inline int halo_cfg_bn(int cfg) { return (cfg == 6 || cfg == 8) ? 64 : 128; }
 inline bool halo_cfg_split(int cfg) { return cfg == 7 || cfg == 8 || cfg == 10; }
 bool halo_geometry(const ConvParams& p, int cfg, HaloGeom* g);
 int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStream_t st);
+
+// Winograd F(2x2, 3x3) form of the same conv (conv3x3_wino.hip): tile_cfg 11.  The transformed filters U = G g G^T live
+// in a "derived" buffer in fragment-major order (wino_weight_floats floats per conv), rebuilt by wino_transform_weights
+// whenever the weights change.
+struct WinoGeom {
+  int TH, TW, NB;        // output pixels per image in the workgroup tile, images per tile
+  int twt, log_twt;      // Winograd (2x2) tiles per tile row
+  int tpi, log_tpi;      // Winograd tiles per image of the workgroup tile
+  int tiles_w, tiles_h;  // workgroup tiles per image
+  int HPI, HP;           // raw halo pixels per image / per workgroup
+};
+bool wino_geometry(const ConvParams& p, WinoGeom* g);
+int wino_stats_slices(const WinoGeom& g);
+long wino_workgroups(const ConvParams& p, const WinoGeom& g);
+int wino_chunks(const ConvParams& p);
+size_t wino_weight_floats(int Cout, int Cin);
+int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st);
+int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
 // partial per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]:

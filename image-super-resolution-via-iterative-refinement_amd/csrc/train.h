@@ -8,7 +8,7 @@ namespace sr3 {
 // overwritten with du, partial sums go to `part`, group sums to gs[B][G][2], parameter gradients to
 // dgamma/dbeta[C], and dx0/dx1 (+=) receive the input gradient.  mr[B][G][2] = (mean, rstd).
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
-            int groups, int act, const float* gamma, double* part, float* gs, float* dgamma, float* dbeta, float* dx0,
+            int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
             float* dx1, hipStream_t st, unsigned drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f);
 // a = dropout(act(x*scale+shift)) over the virtual concat, materialised for the weight-gradient GEMM
 int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, int act, unsigned drop_seed,

@@ -14,6 +14,16 @@
 
 namespace sr3 {
 
+double meant_double(float f) {
+  char buf[40];
+  for (int prec = 1; prec <= 9; ++prec) {
+    snprintf(buf, sizeof(buf), "%.*g", prec, (double)f);
+    const double d = strtod(buf, nullptr);
+    if ((float)d == f) return d;
+  }
+  return (double)f;
+}
+
 __device__ __forceinline__ float sigmoid_t(float v) { return __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -68,9 +78,9 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
           du *= sg * (1.0f + u * (1.0f - sg));
         }
         g4[e] = du;
-        const float xh = (xv[e] - mu[e]) * rs[e];
+        const double xh = ((double)xv[e] - (double)mu[e]) * (double)rs[e];
         s[e] += (double)du;
-        s2[e] += (double)du * (double)xh;
+        s2[e] += (double)du * xh;
       }
       *reinterpret_cast<f32x4*>(dA + pix * C + c) = g4;
     }
@@ -89,9 +99,9 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
   }
 }
 
-// T2a: per (image, group): S1 = sum_c gamma_c * A_c, S2 = sum_c gamma_c * B_c  -> gs[B][G][2] (float)
+// T2a: per (image, group): S1 = sum_c gamma_c * A_c, S2 = sum_c gamma_c * B_c  -> gs[B][G][2] (double)
 __global__ __launch_bounds__(64) void k_gn_bwd_group(const double* __restrict__ part, int C, int T, int groups,
-                                                      const float* __restrict__ gamma, float* __restrict__ gs) {
+                                                      const float* __restrict__ gamma, double* __restrict__ gs) {
   const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
   const int cpg = C / groups;
   const int lane = threadIdx.x;
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(64) void k_gn_bwd_group(const double* __restrict__ 
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m); bb += __shfl_xor(bb, m); }
-  if (lane == 0) { gs[((size_t)b * groups + g) * 2] = (float)a; gs[((size_t)b * groups + g) * 2 + 1] = (float)bb; }
+  if (lane == 0) { gs[((size_t)b * groups + g) * 2] = a; gs[((size_t)b * groups + g) * 2 + 1] = bb; }
 }
 
 // T2b / T8: per channel: out0[c] (+)= sum_{b,t} part[..][c][0] ; out1[c] (+)= sum part[..][c][1]  (either may be null)
@@ -138,16 +148,21 @@ __global__ __launch_bounds__(256) void k_part_imgsum(const double* __restrict__ 
 }
 
 // T3: dx(src) += rstd * (gamma*du - (S1 + xhat*S2)/n), routed to the two concat sources.
+// The two terms cancel heavily (GroupNorm's backward projects the x-hat and the constant component out of du), so the
+// per-(image, group) coefficients stay in double and the expression is evaluated in double and rounded once -- what
+// torch's CPU GroupNorm backward does (acc_type<float> = double for its c1 / c2 / c3 coefficients).  With fp32
+// coefficients the rounding of S2 is a perturbation along x-hat that is coherent over a whole (image, group) and is
+// amplified by sqrt(B H W) in the weight gradient of the conv that produced x (measured 1.2e-4 normwise at B = 64).
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ du, const float* __restrict__ x0,
                                                        const float* __restrict__ x1, int C0, int C1, int HW,
-                                                       const float* __restrict__ mr, const float* __restrict__ gs,
+                                                       const float* __restrict__ mr, const double* __restrict__ gs,
                                                        int groups, const float* __restrict__ gamma,
                                                        float* __restrict__ dx0, float* __restrict__ dx1,
                                                        size_t total4) {
   const int C = C0 + C1;
   const int nq = C >> 2;
   const int cpg = C / groups;
-  const float inv_n = 1.0f / ((float)HW * (float)cpg);
+  const double inv_n = 1.0 / ((double)HW * (double)cpg);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
     const size_t pix = i / nq;
     const int c = (int)(i - pix * nq) * 4;
@@ -162,10 +177,10 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int g = (c + e) / cpg;
-      const float mu = mr[((size_t)b * groups + g) * 2], rs = mr[((size_t)b * groups + g) * 2 + 1];
-      const float S1 = gs[((size_t)b * groups + g) * 2], S2 = gs[((size_t)b * groups + g) * 2 + 1];
-      const float xh = (xv[e] - mu) * rs;
-      o[e] += rs * (gamma[c + e] * g4[e] - (S1 + xh * S2) * inv_n);
+      const double mu = (double)mr[((size_t)b * groups + g) * 2], rs = (double)mr[((size_t)b * groups + g) * 2 + 1];
+      const double S1 = gs[((size_t)b * groups + g) * 2], S2 = gs[((size_t)b * groups + g) * 2 + 1];
+      const double xh = ((double)xv[e] - mu) * rs;
+      o[e] += (float)(rs * ((double)gamma[c + e] * (double)g4[e] - (S1 + xh * S2) * inv_n));
     }
     *reinterpret_cast<f32x4*>(ds + pix * Cs + cs) = o;
   }
@@ -368,7 +383,7 @@ static void stats_geometry(int B, int HW, int C, int* LQ_, int* cblocks_, int* p
 static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b ? b : 1)); }
 
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
-            int groups, int act, const float* gamma, double* part, float* gs, float* dgamma, float* dbeta, float* dx0,
+            int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
             float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
   const int C = C0 + C1;
   if ((C0 & 3) || (C1 & 3)) { set_error("act_bwd: channels %% 4"); return SR3_E_UNSUPPORTED; }
@@ -451,24 +466,14 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, 
               hipStream_t st) {
   if (n & 3) { set_error("adam: n %% 4"); return SR3_E_BADARG; }
   // torch.optim.Adam evaluates 1 - beta, the bias corrections and the step size as Python floats (double) and rounds
-  // each ONCE to fp32 when it meets the tensor.  The ABI carries fp32 hyper-parameters, so first recover the decimal the
-  // caller meant (0.9f -> 0.9, 1e-4f -> 1e-4): the shortest decimal that rounds back to the same float.
-  auto meant = [](float f) {
-    char buf[40];
-    for (int prec = 6; prec <= 9; ++prec) {
-      snprintf(buf, sizeof(buf), "%.*g", prec, (double)f);
-      const double d = strtod(buf, nullptr);
-      if ((float)d == f) return d;
-    }
-    return (double)f;
-  };
-  const double b1d = meant(b1), b2d = meant(b2), lrd = meant(lr);
+  // each ONCE to fp32 when it meets the tensor (meant_double: the decimal behind the ABI's fp32 hyper-parameters).
+  const double b1d = meant_double(b1), b2d = meant_double(b2), lrd = meant_double(lr);
   const double bc1 = 1.0 - pow(b1d, (double)step);
   const double bc2 = 1.0 - pow(b2d, (double)step);
   const float step_size = (float)(lrd / bc1);
   const float bc2s = (float)sqrt(bc2);
   hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n / 4)), dim3(256), 0, st, p, g, m, v, n / 4, (float)(1.0 - b1d), (float)b2d,
-                     (float)(1.0 - b2d), (float)meant(eps), step_size, bc2s);
+                     (float)(1.0 - b2d), (float)meant_double(eps), step_size, bc2s);
   SR3_LAUNCH_CHECK("k_adam");
   return SR3_OK;
 }

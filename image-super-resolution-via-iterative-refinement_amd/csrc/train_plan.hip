@@ -74,8 +74,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   R.temb_off = P->t_temb_off; R.film_off = P->t_film_off; R.scratch_off = P->t_scratch_off; R.scratch_bytes = P->t_scratch_bytes;
   DropCfg dc;
   dc.seed = seed;
-  dc.thresh = dropout_p > 0.f ? (unsigned)((double)dropout_p * 4294967296.0) : 0u;
-  dc.scale = dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f;
+  dropout_consts(dropout_p, &dc.thresh, &dc.scale);
   rc = run_forward(P, R, x_noisy, cond, cond_channels, level, tstep, freq, nullptr, nullptr, params, ws, eps, B, st, nullptr,
                    nullptr, &dc);
   if (rc) return rc;
@@ -91,7 +90,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
 
   float* dA = X.at<float>(P->t_dA_off);
   double* part = X.at<double>(P->t_part_off);
-  float* gs = X.at<float>(P->t_gs_off);
+  double* gs = X.at<double>(P->t_gs_off);
   float* dwtmp = reinterpret_cast<float*>(ws + P->t_dwtmp_off + 4096 * sizeof(double));
 
   int next_mark = 0;

@@ -232,6 +232,7 @@ class EngineDiffusion(nn.Module):
             cond = x_in.to(dev, torch.float32).contiguous()
             shape = tuple(cond.shape)
         st = self._loop_state(shape, None if cond is None else shape, dev)
+        self.denoise_fn.ensure_derived()       # a replayed graph does not pass through EngineUNet.forward
         if x_T is not None:
             st['img'].copy_(x_T)
         else:

@@ -65,6 +65,9 @@ SIGNATURES = {
     'sr3_plan_num_taps': (_I, [_P]),
     'sr3_plan_tap_info': (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_Z), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     'sr3_workspace_bytes': (_Z, [_P, _I]),
+    'sr3_plan_derived_bytes': (_Z, [_P]),
+    'sr3_plan_bind_derived': (_I, [_P, _P, _Z]),
+    'sr3_plan_prepare_derived': (_I, [_P, _P, _P]),
     'sr3_unet_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     'sr3_unet_forward_profile': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P, _I, _P, _P, _P, _P]),
     'sr3_p_sample_step': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
@@ -80,6 +83,7 @@ SIGNATURES = {
                                 _I, _P, _Z, _P]),
     'sr3_conv_dropout_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P,
                                   _I, _I, _P, _Z, C.c_uint, C.c_float, _P]),
+    'sr3_dropout_threshold': (C.c_uint, [C.c_float, C.POINTER(C.c_float)]),
     'sr3_conv_scratch_bytes': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'sr3_groupnorm_stats_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'sr3_groupnorm_stats_slices': (_I, [_I, _I, _I]),

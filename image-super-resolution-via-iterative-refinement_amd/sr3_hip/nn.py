@@ -35,6 +35,11 @@ class EngineUNet(nn.Module):
         self.arena = nn.Parameter(torch.zeros(self.plan.param_floats, dtype=torch.float32), requires_grad=False)
         self.register_buffer('freq', self.plan.default_freq(), persistent=False)
         self._ws = E.Workspace()
+        # derived weights (Winograd-transformed 3x3 filters): engine-owned device buffer, never part of a state dict;
+        # rebuilt whenever the arena content, its storage or the plan options changed
+        self._derived = None
+        self._derived_key = None
+        self._weights_epoch = 0
         self.reset_parameters()
 
     # ---- initialisation: same distributions AND same RNG consumption order as the reference ----
@@ -43,7 +48,7 @@ class EngineUNet(nn.Module):
         construction order so a given torch seed yields the reference's weights."""
         fan_in = 1
         for e in self.plan.table:
-            v = self.plan.view(self.arena.data, e)
+            v = self.plan.view(self.arena.detach(), e)
             name = e['name']
             if _is_norm(name):
                 v.fill_(1.0 if name.endswith('weight') else 0.0)
@@ -68,7 +73,7 @@ class EngineUNet(nn.Module):
             name = e['name']
             if _is_norm(name):
                 continue
-            v = self.plan.view(self.arena.data, e)
+            v = self.plan.view(self.arena.detach(), e)
             if len(e['shape']) >= 2:
                 t = torch.empty(e['shape'], dtype=torch.float32)
                 if init_type == 'orthogonal':
@@ -85,10 +90,39 @@ class EngineUNet(nn.Module):
     def init_orthogonal(self):
         self.init_scheme('orthogonal')
 
+    # ---- derived weights ---------------------------------------------------------------------------
+    def weights_changed(self):
+        """Engine-side writes to the arena through raw pointers (fused Adam) are invisible to torch's version counter:
+        the writer calls this."""
+        self._weights_epoch += 1
+
+    def ensure_derived(self):
+        """(Re)build the Winograd filters if the parameters moved or changed since the last build.  Views handed out by
+        named_parameters()/state-dict loading share the arena's version counter, so in-place edits through them are
+        seen; a no-op (one tuple compare) otherwise."""
+        arena = self.arena
+        if not arena.is_cuda:
+            return
+        key = (arena.data_ptr(), arena._version, self._weights_epoch)
+        if key == self._derived_key:
+            return
+        import ctypes as C
+        lib = self.plan.lib
+        need = int(lib.sr3_plan_derived_bytes(self.plan.handle))
+        if need == 0:
+            self._derived_key = key
+            return
+        if self._derived is None or self._derived.device != arena.device or self._derived.numel() * 4 < need:
+            self._derived = torch.empty((need + 3) // 4, dtype=torch.float32, device=arena.device)
+            L.check(lib.sr3_plan_bind_derived(self.plan.handle, L.ptr(self._derived), self._derived.numel() * 4))
+        stream = C.c_void_p(torch.cuda.current_stream(arena.device).cuda_stream)
+        L.check(lib.sr3_plan_prepare_derived(self.plan.handle, L.ptr(arena), stream))
+        self._derived_key = key
+
     # ---- parameter / state-dict surface --------------------------------------------------------
     def named_parameters(self, prefix='', recurse=True, remove_duplicate=True):
         for e in self.plan.table:
-            yield (prefix + ('.' if prefix else '') + e['name'], self.plan.view(self.arena.data, e))
+            yield (prefix + ('.' if prefix else '') + e['name'], self.plan.view(self.arena.detach(), e))
 
     def parameters(self, recurse=True):
         for _, p in self.named_parameters():
@@ -98,7 +132,7 @@ class EngineUNet(nn.Module):
         if self.variant == 'ddpm':
             destination[prefix + 'time_mlp.0.inv_freq'] = self.freq.detach().clone()
         for e in self.plan.table:
-            destination[prefix + e['name']] = self.plan.view(self.arena.data, e).detach().clone().contiguous()
+            destination[prefix + e['name']] = self.plan.view(self.arena.detach(), e).detach().clone().contiguous()
 
     def state_dict(self, *args, destination=None, prefix='', keep_vars=False):
         # reference key order: buffers of a submodule come after its parameters; rebuild in table order
@@ -121,7 +155,7 @@ class EngineUNet(nn.Module):
                 error_msgs.append('size mismatch for %s: checkpoint %s vs model %s'
                                   % (key, tuple(src.shape), tuple(e['shape'])))
                 continue
-            self.plan.view(self.arena.data, e).copy_(src.to(self.arena.device, torch.float32))
+            self.plan.view(self.arena.detach(), e).copy_(src.to(self.arena.device, torch.float32))
         fkey = prefix + 'time_mlp.0.inv_freq'
         if self.variant == 'ddpm':
             known.add(fkey)
@@ -141,6 +175,7 @@ class EngineUNet(nn.Module):
         `cond`, which the input conv reads as a virtual concat (nothing is materialised).  `ws`: a caller-owned
         engine.Workspace (the captured reverse loop keeps its own so no other call can move the buffer its graph
         has baked in)."""
+        self.ensure_derived()
         kw = {}
         if step_dev is None:
             if self.variant == 'sr3':

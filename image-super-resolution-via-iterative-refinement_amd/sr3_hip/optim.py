@@ -39,6 +39,7 @@ class EngineAdam(object):
         L.check(L.load().sr3_adam_step(L.ptr(arena), L.ptr(un.grad_arena), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                                        arena.numel(), C.c_float(d['lr']), C.c_float(d['betas'][0]),
                                        C.c_float(d['betas'][1]), C.c_float(d['eps']), self.step_count, stream))
+        un.weights_changed()            # the Winograd filters of the inference plan are stale now
 
     # ---- checkpoint format: torch.optim.Adam's (model/model.py:137-142, 160-163) --------------------------
     # One state entry per parameter in `netG.parameters()` order (= the plan table order, which is the

@@ -90,7 +90,7 @@ typedef struct sr3_op_info {
 int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
-/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "loss_l2"};
+/* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd", "loss_l2"};
  * returns previous value.
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
@@ -108,6 +108,14 @@ int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_
 
 /* Workspace bytes for sr3_unet_forward at this batch size (activations, statistics, FiLM table,
  * split-K slabs). */
+/* Derived weights.  The inference plan runs its 3x3 stride-1 convolutions as Winograd F(2x2,3x3) (plan option
+ * "winograd", default 1), which reads the transformed filters U = G g G^T from a caller-owned device buffer of
+ * sr3_plan_derived_bytes bytes (16/9 of the 3x3 weights).  Bind it once (the pointer is kept, and baked into captured
+ * graphs), and re-run sr3_plan_prepare_derived on the stream whenever the parameter arena changed (checkpoint load,
+ * optimizer step): ~55 small launches.  sr3_unet_forward fails with SR3_E_BADARG when a plan needs them and none is bound. */
+size_t sr3_plan_derived_bytes(const sr3_plan* plan);
+int sr3_plan_bind_derived(sr3_plan* plan, void* buffer, size_t bytes);
+int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream);
 size_t sr3_workspace_bytes(sr3_plan* plan, int batch);
 
 /* UNet.forward (model/sr3_modules/unet.py:235-259, model/ddpm_modules/unet.py:220-243).
@@ -195,7 +203,9 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * NHWC in/out, input = virtual concat (src0|src1), optional x2 nearest upsample, stride 1|2,
  * ksize 1|3 (pad ksize/2), prologue act 0 none | 1 x*scale+shift | 2 silu(x*scale+shift) with
  * ss[B][Cin][2]; epilogue + bias + film[b*film_stride+n] + residual (res0|res1 concat view).
- * weights OHWI.  tile_cfg/ksplit 0 = auto.  scratch: split-K slabs (sr3_conv_scratch_bytes). */
+ * weights OHWI.  tile_cfg/ksplit 0 = auto (direct kernels only); tile_cfg 11 = Winograd F(2x2,3x3) (3x3 stride 1, H and W
+ * multiples of 16 or 8x8 maps; the transformed filters are derived into `scratch` by this entry point).
+ * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11), sized by sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
                  int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,
                  int act, const float* film, int film_stride, const float* res0, int RC0, const float* res1,
@@ -219,6 +229,9 @@ int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cou
                          const float* x2_w, const float* x2_bias, float* out, double* out_stats, int tile_cfg,
                          int ksplit, void* scratch, size_t scratch_bytes, unsigned drop_seed, float drop_p,
                          void* stream);
+/* The keep threshold and scale every dropout kernel derives from p: floor(p * 2^32) and 1 / (1 - p), evaluated in double
+ * on the decimal value the fp32 argument stands for (0.2f -> 0.2), as nn.Dropout's p is a Python float.  Host only. */
+unsigned sr3_dropout_threshold(float drop_p, float* scale_out);
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit);
 /* nn.GroupNorm statistics (unet.py:84,119) as PARTIAL per-(image, channel) {sum, sumsq} in double of
  * an NHWC tensor: stat[B][T][C][2] with T = sr3_groupnorm_stats_slices(B, HW, C).  Plain stores (no

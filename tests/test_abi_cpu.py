@@ -158,6 +158,19 @@ def test_plan_launch_list_no_gpu():
     gets, what is fused, and that the opt-in split option only re-targets halo-tile convolutions."""
     from sr3_hip import engine as E
     p = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    # default inference plan: every 3x3 stride-1 conv on the Winograd F(2x2,3x3) kernel (tile 11); the 18 res_convs
+    # of the channel-changing blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
+    wops = p.op_list(16)
+    assert len(wops) == p.num_ops(16) == 169
+    wconvs = [o for o in wops if o['kind'] == 50]
+    for o in wconvs:
+        assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1), o
+        assert not o['fused_res_conv_cin']
+    assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 18
+    assert abs(sum(o['flops'] for o in wops) / 16 / 1e9 - 92.18) < 0.05       # algorithmic FLOPs do not change
+    assert int(p.lib.sr3_plan_derived_bytes(p.handle)) > 0
+    # the direct kernels (plan option winograd = 0; also what the training plan and an explicit tile_cfg use)
+    p.set_option('winograd', 0)
     ops = p.op_list(16)
     assert len(ops) == p.num_ops(16) == 151
     convs = [o for o in ops if o['kind'] == 50]
@@ -227,3 +240,19 @@ def test_plan_options_are_validated():
     assert p.num_ops(2) == n0 and p.workspace_bytes(2) > 0
     with pytest.raises(L.Sr3Error):
         p.workspace_bytes(0)
+
+
+def test_dropout_threshold_matches_the_oracle_mask():
+    """The engine derives its keep threshold from the decimal p the fp32 ABI argument stands for, so its mask is the
+    oracle's (int(p * 2^32) on the Python float) bit for bit -- a threshold off by a few counts flips a handful of mask
+    elements in a 64-image batch and shows up as a 1e-4 relative error in the conv weight gradients of those blocks."""
+    import ctypes as C
+    import numpy as np
+    from sr3_hip import lib as L
+    lib = L.load()
+    for p in (0.2, 0.1, 0.5, 0.25, 0.05, 0.3, 0.123):
+        s = C.c_float()
+        t = lib.sr3_dropout_threshold(C.c_float(p), C.byref(s))
+        assert t == int(p * 4294967296.0), (p, t)
+        assert np.float32(s.value) == np.float32(1.0 / (1.0 - p)), (p, s.value)
+    assert lib.sr3_dropout_threshold(C.c_float(0.0), None) == 0

@@ -130,7 +130,8 @@ def _make_case(case, seed=1):
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2), (5, 1), (6, 1), (5, 2),
-                                             (6, 2), (7, 1), (8, 1), (7, 2), (9, 1), (10, 1), (9, 2), (10, 3)])
+                                             (6, 2), (7, 1), (8, 1), (7, 2), (9, 1), (10, 1), (9, 2), (10, 3),
+                                             (11, 1), (11, 2), (11, 0)])
 def test_conv(case, tile_cfg, ksplit):
     src0, src1, w, kw = _make_case(case)
     total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]
@@ -148,7 +149,7 @@ def test_conv(case, tile_cfg, ksplit):
 
 
 @pytest.mark.parametrize('ksplit', [1, 2])
-@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6, 9, 10])
+@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6, 9, 10, 11])
 @pytest.mark.parametrize('case', [('stats8', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True),
                                   ('stats32', 2, 32, 32, 32, 32, 160, 3, 1, 0, 2, True, True, True),
                                   ('stats_up', 2, 32, 0, 16, 16, 64, 3, 1, 1, 0, False, False, True)],
@@ -174,6 +175,44 @@ def test_conv_fused_output_stats(ksplit, tile_cfg, case):
     s2 = (got.double() ** 2).sum(dim=(2, 3))
     assert torch.allclose(st[:, :, 0], s1, rtol=1e-9, atol=1e-9)
     assert torch.allclose(st[:, :, 1], s2, rtol=1e-9, atol=1e-9)
+
+
+WINO_CASES = [
+    # name, B, C0, C1, H, W, Cout, k, stride, ups, act, film, res, bias  -- the layer shapes of the BASELINE.json networks
+    ('w128_64to64', 2, 64, 0, 128, 128, 64, 3, 1, 0, 2, True, True, True),
+    ('w128_concat192to64', 1, 128, 64, 128, 128, 64, 3, 1, 0, 2, True, False, True),
+    ('w64_up_128to128', 2, 128, 0, 32, 32, 128, 3, 1, 1, 0, False, False, True),
+    ('w32_concat768to256', 1, 512, 256, 32, 32, 256, 3, 1, 0, 2, True, 'res', True),
+    ('w16_512to512', 3, 512, 0, 16, 16, 512, 3, 1, 0, 2, True, True, True),
+    ('w8_1024to512_oddB', 5, 512, 512, 8, 8, 512, 3, 1, 0, 2, True, False, True),
+    ('w16x48_ragged_cout', 2, 24, 8, 16, 48, 40, 3, 1, 0, 2, True, True, True),
+]
+
+
+@pytest.mark.parametrize('ksplit', [0, 1, 3])
+@pytest.mark.parametrize('case', WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_winograd_conv_error_is_fp32_class(case, ksplit):
+    """The Winograd F(2x2,3x3) kernel (tile 11, what the inference plan runs) against a float64 reference next to the
+    direct fp32 MFMA kernels on the same data: same stated tolerance, and its error must stay within a small factor of
+    the direct kernel's (F(2x2,3x3) transforms only use 0, +-1, +-1/2: fp32-class, not a reduced-precision mode)."""
+    src0, src1, w, kw = _make_case(case, seed=7)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    try:
+        got, _ = G.conv_call(src0, src1, w, tile_cfg=11, ksplit=ksplit, **kw)
+    except L.Sr3Error as e:
+        if 'empty split' in str(e):
+            pytest.skip(str(e))
+        raise
+    direct, _ = G.conv_call(src0, src1, w, tile_cfg=0, ksplit=0, **kw)
+    assert not torch.isnan(got).any()
+    e_w = G.assert_close(got, ref, what=case[0] + ' (Winograd)')
+    e_d = G.assert_close(direct, ref, what=case[0] + ' (direct)')
+    rms_w = (got.double() - ref).pow(2).mean().sqrt().item()
+    rms_d = (direct.double() - ref).pow(2).mean().sqrt().item()
+    print('%s ks%d: max/rms err Winograd %.2e/%.2e  direct %.2e/%.2e  |ref|max %.2f'
+          % (case[0], ksplit, e_w, rms_w, e_d, rms_d, ref.abs().max().item()))
+    assert e_w <= 4.0 * e_d + 1e-7 * ref.abs().max().item(), (e_w, e_d)
+    assert rms_w <= 3.0 * rms_d + 1e-8 * ref.abs().max().item(), (rms_w, rms_d)
 
 
 @pytest.mark.parametrize('K', [(64, 0), (512, 0), (512, 512)], ids=['K576', 'K4608', 'K9216'])
