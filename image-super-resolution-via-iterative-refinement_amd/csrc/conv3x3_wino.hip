@@ -13,8 +13,8 @@
 // i.e. 16 independent GEMMs (one per position (i,j) of the 4x4 transform domain)
 //   M_ij[tile][n] = sum_c V_ij[tile][c] * U_ij[n][c],   tile = 2x2 output block, n = output channel, c = input channel.
 //
-// Workgroup = 8 waves (one per CU: 2 waves / SIMD): 64 Winograd tiles (16x16 output pixels of one image, or the 8x8 images
-// of 4 samples) x 64 output channels x all 16 positions.  Wave w owns transform row i = w >> 1 and the two columns
+// Workgroup = 8 waves (one per CU: 2 waves / SIMD): 64 Winograd tiles (16x16 output pixels of one image) x 64 output
+// channels x all 16 positions (8x8 maps keep the direct kernel).  Wave w owns transform row i = w >> 1 and the two columns
 // j = 2 (w & 1), 2 (w & 1) + 1: 2 positions x (64 x 64) outputs = 128 accumulator registers.
 // Per 16-channel chunk of the (virtual concat) input:
 //   1. the raw input halo ((TH+2) x (TW+2) pixels x 16 channels) is staged ONCE by the whole workgroup, GroupNorm
@@ -39,24 +39,26 @@
 namespace sr3 {
 
 namespace {
-constexpr int WT = 64;          // Winograd tiles per workgroup
+constexpr int WT = 64;          // Winograd tiles per workgroup (16 x 16 output pixels)
 constexpr int WBN = 64;         // output channels per workgroup
 constexpr int WCK = 16;         // input channels per chunk
 constexpr int WRS = 20;         // LDS row stride (floats) of the raw halo and of the V planes: 16 + 4 pad
 constexpr int WNT = 512;        // threads (8 waves)
-constexpr int WHP_MAX = 400;    // raw halo pixels: 18 x 18 (one 16x16 tile) or 4 x 10 x 10 (four 8x8 images)
-constexpr int WHI = (WHP_MAX * 4 + WNT - 1) / WNT;   // raw float4 items per thread (4 channel quads per pixel)
+constexpr int WHP = 324;        // raw halo pixels of one tile: 18 x 18
+constexpr int WHI = (WHP * 4 + WNT - 1) / WNT;       // raw float4 items per thread (4 channel quads per pixel)
 constexpr int WLDT = 36;        // epilogue exchange row stride (32 + 4)
-constexpr int W_RAW_F = WHP_MAX * WRS;                // floats
+constexpr int W_RAW_F = WHP * WRS;                    // floats per raw buffer (two of them)
 constexpr int W_V_F = 8 * 2 * WT * WRS;               // 8 waves x 2 positions x 64 tiles x stride
 constexpr int W_EXCH_F = 8 * 2 * 32 * WLDT;           // epilogue: 8 waves x 2 (q) x 32 tiles x stride
-constexpr int W_SMEM_MAIN = (W_RAW_F + W_V_F) * 4;
+constexpr int W_SMEM_MAIN = (2 * W_RAW_F + W_V_F) * 4;
 constexpr int W_SMEM_EPI = W_EXCH_F * 4;               // the exchange block doubles as the statistics parking area
 constexpr int W_SMEM = W_SMEM_MAIN > W_SMEM_EPI ? W_SMEM_MAIN : W_SMEM_EPI;
-constexpr int W_SS4_CIN = 1024;                       // NSLOT == 4: scale/shift of 4 images x Cin channels in LDS
-constexpr int W_SMEM4 = W_SMEM_MAIN + 4 * W_SS4_CIN * 2 * 4;
 
-__device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+// x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e): ~1e-7 absolute error on silu, three instructions
+// instead of libm expf's twelve -- every staged element pays for this once per output-channel block
+__device__ __forceinline__ float silu_w(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -127,13 +129,13 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int NSLOT>        // image slots a workgroup tile can span (1: 16x16 tiles, 4: 8x8 images)
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
-  float* raw = smem;                              // [HP][WRS]
-  float* vbase = smem + W_RAW_F;                  // [8 waves][2][64][WRS]
+  float* raw0 = smem;                             // [WHP][WRS] x 2 (double buffered)
+  float* raw1 = smem + W_RAW_F;
+  float* vbase = smem + 2 * W_RAW_F;              // [8 waves][2][64][WRS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Cin = p.C0 + p.C1;
@@ -142,15 +144,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; give each XCD one contiguous range of the
   // (cout block major) tile list so that the U fragments of a cout block stay inside one L2
   if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
-  const int sp_tiles = g.tiles_w * g.tiles_h * ((p.B + g.NB - 1) / g.NB);
+  const int sp_tiles = g.tiles_w * g.tiles_h * p.B;
   const int cb = bid / sp_tiles;
   int sp = bid - cb * sp_tiles;
   const int tw_i = sp % g.tiles_w;
   sp /= g.tiles_w;
   const int th_i = sp % g.tiles_h;
-  const int tb_i = sp / g.tiles_h;
-  const int h0 = th_i * g.TH, w0 = tw_i * g.TW, b0 = tb_i * g.NB;
-  const int TWp = g.TW + 2;
+  const int b0 = sp / g.tiles_h;                  // one image per tile
+  const int h0 = th_i * 16, w0 = tw_i * 16;
+  constexpr int TWp = 18;
 
   const int nch = (Cin + WCK - 1) / WCK;
   const int cper = (nch + p.ksplit - 1) / p.ksplit;
@@ -160,44 +162,25 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // ---- raw staging items of this thread: item j covers halo pixel (tid >> 2) + 128 j, channel quad tid & 3 ----
   const int kq = tid & 3, lrow = tid >> 2;
   int hpix[WHI];
-  int himg[WHI];
 #pragma unroll
   for (int j = 0; j < WHI; ++j) {
     const int hp = lrow + (WNT / 4) * j;
-    int pix = -1, nb = 0;
-    if (hp < g.HP) {
-      nb = hp / g.HPI;
-      const int r = hp - nb * g.HPI;
-      const int hy = r / TWp, hx = r - hy * TWp;
+    int pix = -1;
+    if (hp < WHP) {
+      const int hy = hp / TWp, hx = hp - hy * TWp;
       const int ih = h0 + hy - 1, iw = w0 + hx - 1;
-      const int b = b0 + nb;
-      if (b < p.B && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        pix = (b * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        pix = (b0 * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
     }
     hpix[j] = pix;
-    himg[j] = nb;
   }
   f32x4 rh[WHI];
-  f32x4 ssa, ssb;           // NSLOT == 1: scale/shift of this thread's channel quad (one image per tile)
-  // NSLOT == 4 (four 8x8 images per tile): the whole scale/shift table of the tile's images sits in LDS, [4][Cin][2]
-  float* ssl = smem + W_RAW_F + W_V_F;
-  if (NSLOT == 4 && p.act != 0) {
-    const int per = Cin * 2 / 4;                     // float4 per image
-    for (int i = tid; i < 4 * per; i += WNT) {
-      const int sl = i / per, o = i - sl * per;
-      const int b = min(b0 + sl, p.B - 1);
-      *reinterpret_cast<f32x4*>(ssl + ((size_t)sl * Cin) * 2 + o * 4) =
-          *reinterpret_cast<const f32x4*>(p.ss + ((size_t)b * Cin) * 2 + o * 4);
-    }
-    __syncthreads();
-  }
+  f32x4 ssa, ssb;           // scale/shift of this thread's channel quad
   bool hvalid = false;
-  int cur_c = 0;
   auto load_raw = [&](int chunk) {
     const int c = chunk * WCK + kq * 4;
     hvalid = c < Cin;
     const int ce = hvalid ? c : 0;
-    cur_c = ce;
     const bool second = ce >= p.C0;
     const float* sp_ = second ? p.src1 : p.src0;
     const int sC = second ? p.C1 : p.C0;
@@ -207,30 +190,24 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       const int off = hpix[j] >= 0 ? hpix[j] * sC + cs : 0;
       rh[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
     }
-    if (NSLOT == 1 && p.act != 0) {
-      const float* q = p.ss + ((size_t)min(b0, p.B - 1) * Cin + ce) * 2;
+    if (p.act != 0) {
+      const float* q = p.ss + ((size_t)b0 * Cin + ce) * 2;
       ssa = *reinterpret_cast<const f32x4*>(q);
       ssb = *reinterpret_cast<const f32x4*>(q + 4);
     }
   };
-  auto store_raw = [&]() {
+  auto store_raw = [&](float* raw) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
       const int hp = lrow + (WNT / 4) * j;
-      if (hp < g.HP) {
+      if (hp < WHP) {
         f32x4 v = rh[j];
         if (p.act != 0) {
-          f32x4 sa = ssa, sb = ssb;
-          if (NSLOT == 4) {
-            const float* q = ssl + ((size_t)himg[j] * Cin + cur_c) * 2;
-            sa = *reinterpret_cast<const f32x4*>(q);
-            sb = *reinterpret_cast<const f32x4*>(q + 4);
-          }
-          v.x = fmaf(v.x, sa.x, sa.y);
-          v.y = fmaf(v.y, sa.z, sa.w);
-          v.z = fmaf(v.z, sb.x, sb.y);
-          v.w = fmaf(v.w, sb.z, sb.w);
+          v.x = fmaf(v.x, ssa.x, ssa.y);
+          v.y = fmaf(v.y, ssa.z, ssa.w);
+          v.z = fmaf(v.z, ssb.x, ssb.y);
+          v.w = fmaf(v.w, ssb.z, ssb.w);
           if (p.act == 2) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
@@ -245,47 +222,42 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
   const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
   const float rsgn = (wi == 1) ? 1.f : -1.f;
-  // lane = tile: raw pixel of the patch origin
-  int tile_hb;
-  {
-    const int nb = lane >> g.log_tpi;
-    const int r = lane & (g.tpi - 1);
-    const int ty = r >> g.log_twt, tx = r & (g.twt - 1);
-    tile_hb = nb * g.HPI + (2 * ty) * TWp + 2 * tx;
-  }
-  const int rot = (lane >> 3) & 3;                  // per-lane channel-quad rotation: spreads the LDS banks
+  // lane = tile (8 x 8 tiles of 2x2 outputs): float offset of the two patch rows this wave combines
+  const int ty = lane >> 3, tx = lane & 7;
+  const int offa = ((2 * ty + ra) * TWp + 2 * tx + wh) * WRS;
+  const int offb = ((2 * ty + rb) * TWp + 2 * tx + wh) * WRS;
+  const int rot = ty & 1;                           // per-lane channel-quad swap inside a half chunk: spreads the LDS banks
   float* vw = vbase + wave * (2 * WT * WRS);        // this wave's two V planes [2][64][WRS]
-  auto transform = [&]() {
-    const float* pa = raw + (tile_hb + ra * TWp + wh) * WRS;
-    const float* pb = raw + (tile_hb + rb * TWp + wh) * WRS;
+  // the transform of one channel quad, split so that its six LDS reads can be in flight across an MFMA block:
+  //   t_load issues the reads, t_finish does the row pass (3 FMAs), the column pass (2 adds) and the two LDS writes
+  auto t_load = [&](const float* rawbuf, int cq, f32x4 (&da)[3], f32x4 (&db)[3]) {
 #pragma unroll
-    for (int q0 = 0; q0 < 4; ++q0) {
-      const int cq = (q0 + rot) & 3;
-      f32x4 t[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const f32x4 da = *reinterpret_cast<const f32x4*>(pa + s * WRS + cq * 4);
-        const f32x4 db = *reinterpret_cast<const f32x4*>(pb + s * WRS + cq * 4);
-        t[s] = da + db * rsgn;
-      }
-      // wh == 0: columns j = 0, 1 from t0, t1, t2:  V0 = t0 - t2, V1 = t1 + t2
-      // wh == 1: columns j = 2, 3 from t1, t2, t3:  V2 = t2 - t1, V3 = t1 - t3     (t[] = t1, t2, t3)
-      const f32x4 va = wh == 0 ? t[0] - t[2] : t[1] - t[0];
-      const f32x4 vb = wh == 0 ? t[1] + t[2] : t[0] - t[2];
-      *reinterpret_cast<f32x4*>(vw + (0 * WT + lane) * WRS + cq * 4) = va;
-      *reinterpret_cast<f32x4*>(vw + (1 * WT + lane) * WRS + cq * 4) = vb;
+    for (int s = 0; s < 3; ++s) {
+      da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + s * WRS + cq * 4);
+      db[s] = *reinterpret_cast<const f32x4*>(rawbuf + offb + s * WRS + cq * 4);
     }
+  };
+  auto t_finish = [&](int cq, const f32x4 (&da)[3], const f32x4 (&db)[3]) {
+    f32x4 t[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) t[s] = da[s] + db[s] * rsgn;
+    // wh == 0: columns j = 0, 1 from t0, t1, t2:  V0 = t0 - t2, V1 = t1 + t2
+    // wh == 1: columns j = 2, 3 from t1, t2, t3:  V2 = t2 - t1, V3 = t1 - t3     (t[] = t1, t2, t3)
+    const f32x4 va = wh == 0 ? t[0] - t[2] : t[1] - t[0];
+    const f32x4 vb = wh == 0 ? t[1] + t[2] : t[0] - t[2];
+    *reinterpret_cast<f32x4*>(vw + (0 * WT + lane) * WRS + cq * 4) = va;
+    *reinterpret_cast<f32x4*>(vw + (1 * WT + lane) * WRS + cq * 4) = vb;
   };
 
   // ---- U fragments: [pj][nblk][kk] float4, straight from global in fragment-major order ----
   f32x4 u[2][2][2];
   const float* ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + lane * 4;
-  auto load_u = [&](int chunk, int pj) {
-    const float* q = ubase + (size_t)chunk * 16 * 1024 + pj * 1024;
+  auto load_u = [&](int chunk, int kk) {             // the four fragments of half a chunk (channels 8 kk .. 8 kk + 7)
+    const float* q = ubase + (size_t)chunk * 16 * 1024;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int pj = 0; pj < 2; ++pj)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) u[pj][n][kk] = *reinterpret_cast<const f32x4*>(q + (n * 2 + kk) * 256);
+      for (int n = 0; n < 2; ++n) u[pj][n][kk] = *reinterpret_cast<const f32x4*>(q + pj * 1024 + (n * 2 + kk) * 256);
   };
 
   f32x16 acc[2][2][2];          // [pj][mblk][nblk]
@@ -298,41 +270,76 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
   const int kh = (lane >> 5) * 4;
+  auto mfma_block = [&](int pj, int kk) {            // 16 MFMAs: this wave's position pj, channels 8 kk .. 8 kk + 7
+    f32x4 a[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      a[m] = *reinterpret_cast<const f32x4*>(vw + (pj * WT + m * 32 + (lane & 31)) * WRS + kk * 8 + kh);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], u[pj][n][kk][q], acc[pj][m][n], 0, 0, 0);
+  };
 
-  if (c_begin < c_end) {
+  // ---- main loop, software pipelined over half chunks -----------------------------------------------------------
+  // Chunk i's raw tile lives in raw[i & 1].  V holds channel quads {0,1} (kk = 0) and {2,3} (kk = 1) of both positions;
+  // a half is rebuilt for the NEXT use as soon as its two MFMA blocks are done, with the six LDS reads of every quad
+  // issued before an MFMA block and consumed after it:
+  //   block A(i): MFMA (pj 0|1, kk 0)   ||  transform half kk 1 of chunk i     (reads raw[i & 1])
+  //   barrier                               raw[i & 1] is free -> stage chunk i + 2 into it; chunk i + 1 is visible
+  //   block B(i): MFMA (pj 0|1, kk 1)   ||  transform half kk 0 of chunk i + 1 (reads raw[(i + 1) & 1])
+  const int nck = c_end - c_begin;
+  if (nck > 0) {
     load_raw(c_begin);
+    store_raw(raw0);
+    if (nck > 1) { load_raw(c_begin + 1); store_raw(raw1); }
+    if (nck > 2) load_raw(c_begin + 2);
     load_u(c_begin, 0);
     load_u(c_begin, 1);
-    store_raw();
     __syncthreads();
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-      const bool more = chunk + 1 < c_end;
-      transform();                                  // raw -> this wave's V planes (wave-private)
-      __syncthreads();                              // every wave is done reading the raw tile
-      // NSLOT == 1: the next raw chunk is in flight across the MFMA block.  The four-image form (8x8 layers, 4 % of
-      // the FLOPs) has no registers left for that and loads after the block instead.
-      if (NSLOT == 1 && more) load_raw(chunk + 1);
-#pragma unroll
-      for (int pj = 0; pj < 2; ++pj) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          f32x4 a[2];
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            a[m] = *reinterpret_cast<const f32x4*>(vw + (pj * WT + m * 32 + (lane & 31)) * WRS + kk * 8 + kh);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-              for (int n = 0; n < 2; ++n)
-                acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], u[pj][n][kk][q], acc[pj][m][n], 0, 0, 0);
-        }
-        if (more) load_u(chunk + 1, pj);            // this position's fragments are consumed: refill for the next chunk
-      }
-      if (NSLOT != 1 && more) load_raw(chunk + 1);
-      if (more) store_raw();
+    {
+      f32x4 da[3], db[3];
+      t_load(raw0, rot, da, db);
+      t_finish(rot, da, db);
+      t_load(raw0, rot ^ 1, da, db);
+      t_finish(rot ^ 1, da, db);
+    }
+    for (int i = 0; i < nck; ++i) {
+      float* rcur = (i & 1) ? raw1 : raw0;
+      const float* rnext = (i & 1) ? raw0 : raw1;
+      const bool more = i + 1 < nck;
+      f32x4 da[3], db[3];
+      // block A  (sched_barrier: keep the transform's LDS reads ahead of the MFMA block and its arithmetic behind it --
+      // left alone the scheduler sinks the reads below the MFMAs and waits on them at once)
+      t_load(rcur, 2 + rot, da, db);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      t_finish(2 + rot, da, db);
+      t_load(rcur, 2 + (rot ^ 1), da, db);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      t_finish(2 + (rot ^ 1), da, db);
+      if (more) load_u(c_begin + i + 1, 0);
       __syncthreads();
+      if (i + 2 < nck) {
+        store_raw(rcur);
+        if (i + 3 < nck) load_raw(c_begin + i + 3);
+      }
+      // block B
+      if (more) t_load(rnext, rot, da, db);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { t_finish(rot, da, db); t_load(rnext, rot ^ 1, da, db); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_block(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { t_finish(rot ^ 1, da, db); load_u(c_begin + i + 1, 1); }
     }
   }
 
@@ -351,15 +358,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // final-combine mapping: thread -> (p, q) sub-pixel of the 2x2 block, 16 tile rows x 8 channel quads, two tile halves e
   const int pq = tid >> 7, fp = pq >> 1, fq = pq & 1;
   const int ftile = (tid & 127) >> 3, fcq = tid & 7;
-  const int T = NSLOT == 1 ? g.tiles_h * g.tiles_w : 1;            // statistics partials per image
-  const int tix = NSLOT == 1 ? th_i * g.tiles_w + tw_i : 0;
+  const int T = g.tiles_h * g.tiles_w;                             // statistics partials per image
+  const int tix = th_i * g.tiles_w + tw_i;
 #pragma unroll
   for (int nblk = 0; nblk < 2; ++nblk) {
     const int n = cb * WBN + nblk * 32 + fcq * 4;
     const bool nok = n < p.Cout;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-    double tot1 = 0.0, tot2 = 0.0;                  // NSLOT == 1 writer threads: running sums over the two tile blocks
+    double tot1 = 0.0, tot2 = 0.0;                  // writer threads: running sums over the two tile blocks
 #pragma unroll
     for (int mblk = 0; mblk < 2; ++mblk) {
       f32x16 p0, p1;
@@ -391,11 +398,9 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         };
         const f32x4 r0 = rd(0, 0) + rd(0, 1), r1 = rd(1, 0) + rd(1, 1), r2 = rd(2, 0) + rd(2, 1), r3 = rd(3, 0) + rd(3, 1);
         f32x4 v = fp == 0 ? (r0 + r1) + r2 : (r1 - r2) - r3;
-        const int tau = mblk * 32 + trow;
-        const int nb = tau >> g.log_tpi;
-        const int rr = tau & (g.tpi - 1);
-        const int ty = rr >> g.log_twt, tx = rr & (g.twt - 1);
-        const int b = b0 + nb;
+        const int tau = mblk * 32 + trow;                // tile of the 8 x 8 grid
+        const int ty = tau >> 3, tx = tau & 7;
+        const int b = b0;
         if (b < p.B && nok) {
           const size_t pix = ((size_t)b * H + (h0 + 2 * ty + fp)) * W + (w0 + 2 * tx + fq);
           if (direct) {
@@ -415,10 +420,9 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       }
       __syncthreads();                                  // every read of the exchange block is complete
       if (stats) {
-        // Per-(image, channel) sums of this block's outputs, reduced in a fixed order: every thread parks its two
-        // accumulator sets in the (now free) exchange region, then one thread per (channel, tile half) walks the 64
-        // threads that share its channel quad.  A tile half e of block mblk is image slot 2 mblk + e when the tile spans
-        // 4 images (NSLOT == 4); with one image per tile (NSLOT == 1) all four (mblk, e) sets belong to the same image.
+        // Per-channel sums of this block's outputs (one image per tile), reduced in a fixed order: every thread parks its
+        // two accumulator sets in the (now free) exchange region, then one thread per (channel, tile half) walks the 64
+        // threads that share its channel quad; the two halves and the two tile blocks are folded by the writer.
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -433,22 +437,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
             a1 += part[(t * 2 + e) * 8 + (c & 3)];
             a2 += part[(t * 2 + e) * 8 + 4 + (c & 3)];
           }
+          a1 += __shfl_xor(a1, 32);                     // lanes 0-31: e = 0, lanes 32-63: e = 1
+          a2 += __shfl_xor(a2, 32);
+          tot1 += a1; tot2 += a2;
           const int nn = cb * WBN + nblk * 32 + c;
-          if (NSLOT == 1) {
-            // lanes 0-31 hold e = 0, lanes 32-63 e = 1 of the same wave: fold, then accumulate over the two blocks
-            a1 += __shfl_xor(a1, 32);
-            a2 += __shfl_xor(a2, 32);
-            tot1 += a1; tot2 += a2;
-            if (mblk == 1 && e == 0 && nn < p.Cout && b0 < p.B) {
-              double* o = p.ostat + (((size_t)b0 * T + tix) * p.Cout + nn) * 2;
-              o[0] = tot1; o[1] = tot2;
-            }
-          } else {
-            const int b = b0 + mblk * 2 + e;
-            if (nn < p.Cout && b < p.B) {
-              double* o = p.ostat + (((size_t)b * T + tix) * p.Cout + nn) * 2;
-              o[0] = a1; o[1] = a2;
-            }
+          if (mblk == 1 && e == 0 && nn < p.Cout) {
+            double* o = p.ostat + (((size_t)b0 * T + tix) * p.Cout + nn) * 2;
+            o[0] = tot1; o[1] = tot2;
           }
         }
         __syncthreads();                                // the parked sums are consumed before the next block is written
@@ -466,19 +461,18 @@ bool wino_geometry(const ConvParams& p, WinoGeom* g) {
   if (p.ksize != 3 || p.stride != 1) return false;
   const int H = p.Ho, W = p.Wo;
   if (H != (p.Hs << p.ups) || W != (p.Ws << p.ups)) return false;
-  if (W >= 16 && (W % 16) == 0 && (H % 16) == 0) { g->TH = 16; g->TW = 16; g->NB = 1; }
-  else if (W == 8 && H == 8 && p.C0 + p.C1 <= 1024) { g->TH = 8; g->TW = 8; g->NB = 4; }
-  else return false;
-  g->twt = g->TW / 2; g->log_twt = ilog2x(g->twt);
-  g->tpi = (g->TH / 2) * (g->TW / 2); g->log_tpi = ilog2x(g->tpi);
-  g->tiles_w = W / g->TW; g->tiles_h = H / g->TH;
-  g->HPI = (g->TH + 2) * (g->TW + 2);
-  g->HP = g->HPI * g->NB;
-  return g->HP <= WHP_MAX;
+  if (W < 16 || (W % 16) != 0 || (H % 16) != 0) return false;     // 8x8 maps stay on the direct kernel (no gain measured)
+  g->TH = 16; g->TW = 16; g->NB = 1;
+  g->twt = 8; g->log_twt = 3;
+  g->tpi = 64; g->log_tpi = 6;
+  g->tiles_w = W / 16; g->tiles_h = H / 16;
+  g->HPI = WHP;
+  g->HP = WHP;
+  return true;
 }
-int wino_stats_slices(const WinoGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 1; }
+int wino_stats_slices(const WinoGeom& g) { return g.tiles_h * g.tiles_w; }
 long wino_workgroups(const ConvParams& p, const WinoGeom& g) {
-  return (long)((p.Cout + WBN - 1) / WBN) * g.tiles_w * g.tiles_h * ((p.B + g.NB - 1) / g.NB);
+  return (long)((p.Cout + WBN - 1) / WBN) * g.tiles_w * g.tiles_h * p.B;
 }
 int wino_chunks(const ConvParams& p) { return (p.C0 + p.C1 + WCK - 1) / WCK; }
 
@@ -490,15 +484,9 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const int nch = wino_chunks(p);
   if (p.ksplit > 1 && (long)(p.ksplit - 1) * ((nch + p.ksplit - 1) / p.ksplit) >= nch) { set_error("conv: ksplit %d leaves an empty split over %d chunks", p.ksplit, nch); return SR3_E_BADARG; }
   dim3 grid((unsigned)wino_workgroups(p, g), p.ksplit);
-  if (g.NB == 1) {
-    static std::atomic<uint64_t> done1{0};
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<1>), W_SMEM, done1)) return rc;
-    hipLaunchKernelGGL(k_conv3x3_wino<1>, grid, dim3(WNT), W_SMEM, st, p, g, ufrag);
-  } else {
-    static std::atomic<uint64_t> done4{0};
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<4>), W_SMEM4, done4)) return rc;
-    hipLaunchKernelGGL(k_conv3x3_wino<4>, grid, dim3(WNT), W_SMEM4, st, p, g, ufrag);
-  }
+  static std::atomic<uint64_t> done{0};
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino), W_SMEM, done)) return rc;
+  hipLaunchKernelGGL(k_conv3x3_wino, grid, dim3(WNT), W_SMEM, st, p, g, ufrag);
   SR3_LAUNCH_CHECK("k_conv3x3_wino");
   return SR3_OK;
 }

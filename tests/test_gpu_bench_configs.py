@@ -9,9 +9,9 @@ CPU oracle on the same seeded inputs:
       vs torch autograd over the oracle, evaluated in 8 chunks of 8 images (the gradient of the sum-reduced loss is
       the sum over chunks; the dropout mask is a function of the element's index in the full batch).
 
-The plans at these batch sizes pick other tiles than at batch 1 (8-wave 256x128 tile, split-K 2/4/8/16 on the small
-layers, the 8-wave 64x32 dropout form) -- each test asserts the plan really contains them, so a heuristic change
-that silently moves the bench onto untested kernels fails here.
+The plans at these batch sizes pick other kernels than at batch 1 (the Winograd kernel with and without split-K, the
+8-wave 256x128 direct tile, split-K 2/4/8/16 on the small layers, the 8-wave 64x32 dropout form) -- each test asserts
+the plan really contains them, so a heuristic change that silently moves the bench onto untested kernels fails here.
 Tolerances: forward / step 2e-5 * max(1, |ref|_inf); loss rel 1e-5; gradients normwise rel 1e-4."""
 import pytest
 import torch
@@ -85,8 +85,9 @@ def test_c2_batch16_forward_and_graph_step():
     B = 16
     netG, sd, desc, opt, c = _build('sr3_16_128')
     cfgs = _cfgs(netG, B)
-    # the bench plan: 8-wave 256x128 tile, 256x64 tile, 128x128 tile with split-K up to 16
-    assert (9, 1) in cfgs and (6, 1) in cfgs and any(t == 5 and k >= 8 for t, k in cfgs), sorted(set(cfgs))
+    # the bench plan: Winograd F(2x2,3x3) kernel (tile 11) on the 128^2 .. 16^2 layers (split-K 2 at 16^2), the direct
+    # 128x128 halo tile with split-K >= 8 on the 8^2 layers
+    assert (11, 1) in cfgs and (11, 2) in cfgs and any(t == 5 and k >= 8 for t, k in cfgs), sorted(set(cfgs))
     d = G.dev()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 6, 128, 128, generator=g)
@@ -97,13 +98,22 @@ def test_c2_batch16_forward_and_graph_step():
     err = G.assert_close(got, ref, what='C2 batch 16 eps')
     print('C2 batch 16: eps max abs err %.2e (|ref|max %.2f)' % (err, ref.abs().max().item()))
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2')
+    # the direct-convolution plan at the same batch (plan option winograd = 0: what the training plan's forward and data
+    # gradients run on): 8-wave 256x128 tile, 256x64 tile, 128x128 tile with split-K
+    netG.denoise_fn.plan.set_option('winograd', 0)
+    cfgs = _cfgs(netG, B)
+    assert (9, 1) in cfgs and (6, 1) in cfgs and any(t == 5 and k >= 8 for t, k in cfgs), sorted(set(cfgs))
+    got = netG.denoise_fn(x.to(d), lvl.to(d)).cpu()
+    err = G.assert_close(got, ref, what='C2 batch 16 eps (direct kernels)')
+    print('C2 batch 16, direct kernels: eps max abs err %.2e' % err)
+    netG.denoise_fn.plan.set_option('winograd', 1)
 
 
 def test_c4_batch4_graph_step():
     B = 4
     netG, sd, desc, opt, c = _build('sr3_64_512')
     cfgs = _cfgs(netG, B)
-    assert any(t == 9 for t, _ in cfgs) and any(t == 6 for t, _ in cfgs), sorted(set(cfgs))
+    assert any(t == 11 for t, _ in cfgs), sorted(set(cfgs))
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 777, 'C4')
 
 

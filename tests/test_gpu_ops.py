@@ -184,7 +184,7 @@ WINO_CASES = [
     ('w64_up_128to128', 2, 128, 0, 32, 32, 128, 3, 1, 1, 0, False, False, True),
     ('w32_concat768to256', 1, 512, 256, 32, 32, 256, 3, 1, 0, 2, True, 'res', True),
     ('w16_512to512', 3, 512, 0, 16, 16, 512, 3, 1, 0, 2, True, True, True),
-    ('w8_1024to512_oddB', 5, 512, 512, 8, 8, 512, 3, 1, 0, 2, True, False, True),
+    ('w16_1024to512_oddB', 3, 512, 512, 16, 16, 512, 3, 1, 0, 2, True, False, True),
     ('w16x48_ragged_cout', 2, 24, 8, 16, 48, 40, 3, 1, 0, 2, True, True, True),
 ]
 

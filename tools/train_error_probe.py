@@ -21,6 +21,8 @@ def main():
     ap.add_argument('--config', default='sr3_16_128')
     ap.add_argument('--chunk', type=int, default=8)
     ap.add_argument('--top', type=int, default=12)
+    ap.add_argument('--offset', type=int, default=0, help='first sample of the seeded 64-sample set to use')
+    ap.add_argument('--variant', action='append', default=[], help='extra engine runs with plan options, e.g. ksplit=1,fuse_stats=0')
     a = ap.parse_args()
     from oracle import sr3_oracle as O
     if a.config in ('sr3_tiny', 'sr3_seam'):
@@ -42,13 +44,25 @@ def main():
     d = torch.device('cuda:0')
     B, S, seed = a.batch, c['size'], 20240607
     g = torch.Generator().manual_seed(8)
-    hr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
-    sr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
-    z = torch.randn(B, 3, S, S, generator=g)
-    gamma = torch.rand(B, generator=g) * 0.9 + 0.05
+    NB = max(64, B + a.offset)
+    hr = (torch.rand(NB, 3, S, S, generator=g) * 2 - 1)[a.offset:a.offset + B]
+    sr = (torch.rand(NB, 3, S, S, generator=g) * 2 - 1)[a.offset:a.offset + B]
+    z = torch.randn(NB, 3, S, S, generator=g)[a.offset:a.offset + B]
+    gamma = (torch.rand(NB, generator=g) * 0.9 + 0.05)[a.offset:a.offset + B]
+    print('gamma', [round(float(x), 3) for x in gamma])
     loss = netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), gamma=gamma, drop_seed=seed)
     torch.cuda.synchronize()
     got = {k: v.cpu().double() for k, v in netG.denoise_fn.named_gradients()}
+    variants = {}
+    for var in a.variant:
+        for kv in var.split(','):
+            k, v = kv.split('=')
+            netG.denoise_fn.plan.set_option(k, int(v))
+        netG.p_losses({'HR': hr.to(d), 'SR': sr.to(d)}, noise=z.to(d), gamma=gamma, drop_seed=seed)
+        torch.cuda.synchronize()
+        variants[var] = {k: v.cpu().double() for k, v in netG.denoise_fn.named_gradients()}
+        for kv in var.split(','):
+            netG.denoise_fn.plan.set_option(kv.split('=')[0], 0 if kv.split('=')[0] != 'fuse_stats' else 1)
     res = {}
     for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
         t0 = time.time()
@@ -78,6 +92,9 @@ def main():
     print('worst by oracle32-vs-f64:')
     for r in rows[:8]:
         print('  %.2e  %.2e  %.2e  %s' % r)
+    for var, gv in variants.items():
+        vr = sorted((((gv[k] - r).norm().item() / max(r.norm().item(), 1e-30)), k) for k, r in ref.items())
+        print('variant %s: worst engine_vs_f64 %.2e (%s), median %.2e' % (var, vr[-1][0], vr[-1][1], vr[len(vr) // 2][0]))
     import statistics
     print('median engine_vs_f64 %.2e, median oracle32_vs_f64 %.2e' % (statistics.median(r[0] for r in rows),
                                                                       statistics.median(r[1] for r in rows)))

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box, seconds): the batch-B training gradients of the engine against the SUM of the engine's own
+gradients over sub-batches of 16 (dropout 0, same per-sample gamma / noise), optionally with plan options forced for the
+big run -- isolates batch-size-dependent kernel choices.
+  python tools/train_selfcheck.py --batch 64 [--opt tile_cfg=5 --opt ksplit=1]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+import torch                                      # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--sub', type=int, default=16)
+    ap.add_argument('--config', default='sr3_16_128')
+    ap.add_argument('--opt', action='append', default=[])
+    ap.add_argument('--top', type=int, default=8)
+    a = ap.parse_args()
+    from test_gpu_bench_configs import _build
+    netG, sd, desc, opt, c = _build(a.config, phase='train', seed=17, dropout=0.0)
+    netG.train()
+    d = torch.device('cuda:0')
+    B, S = a.batch, c['size']
+    g = torch.Generator().manual_seed(8)
+    hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(d)
+    sr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(d)
+    z = torch.randn(B, 3, S, S, generator=g).to(d)
+    gamma = torch.rand(B, generator=g) * 0.9 + 0.05
+    un = netG.denoise_fn
+    ref = None
+    for lo in range(0, B, a.sub):
+        sl = slice(lo, lo + a.sub)
+        netG.p_losses({'HR': hr[sl], 'SR': sr[sl]}, noise=z[sl], gamma=gamma[sl])
+        torch.cuda.synchronize()
+        gsub = un.grad_arena.double() * (a.sub / B)
+        ref = gsub if ref is None else ref + gsub
+    for kv in a.opt:
+        k, v = kv.split('=')
+        un.plan.set_option(k, int(v))
+    netG.p_losses({'HR': hr, 'SR': sr}, noise=z, gamma=gamma)
+    torch.cuda.synchronize()
+    got = un.grad_arena.double()
+    rows = []
+    for e in un.plan.table:
+        r = ref[e['offset']:e['offset'] + e['numel']]
+        q = got[e['offset']:e['offset'] + e['numel']]
+        den = max(r.norm().item(), 1e-30)
+        rows.append(((q - r).norm().item() / den, e['name'], den, (q - r).abs().max().item()))
+    rows.sort(reverse=True)
+    print('B=%d vs sum of B=%d runs, options %s: worst relative differences' % (B, a.sub, a.opt))
+    for r in rows[:a.top]:
+        print('  %.2e  %-52s |ref| %.3e  max abs diff %.3e' % r)
+    import statistics
+    print('median %.2e' % statistics.median(r[0] for r in rows))
+
+
+if __name__ == '__main__':
+    main()
