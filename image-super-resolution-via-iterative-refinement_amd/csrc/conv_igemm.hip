@@ -325,11 +325,12 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   const int Cin = p.C0 + p.C1;
   const int taps = p.ksize * p.ksize;
   const int nchunks = cdiv(Cin, 32);
+  static const bool no_wide = getenv("SR3_NO_WIDE") != nullptr;     // A/B knob: never pick the 8-wave 256x128 tile
   if (tile_cfg == 0) {
     HaloGeom g;
     if (p.ksize == 3 && p.stride == 1) {
       if (p.Cout <= 64 && halo_geometry(p, 6, &g)) tile_cfg = 6;
-      else if (p.Cout > 64 && halo_geometry(p, 9, &g) &&
+      else if (p.Cout > 64 && !no_wide && halo_geometry(p, 9, &g) &&
                (long)cdiv(p.Cout, 128) * g.tiles_w * g.tiles_h * cdiv(p.B, g.NB) >= 256)
         tile_cfg = 9;     // 8-wave 256x128 tile: half the weight traffic, when it still fills every CU
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;

@@ -361,10 +361,11 @@ struct Builder {
     ops.push_back(o);
     max_cin = std::max(max_cin, Cf);
   }
-  // inference plans run every 3x3 stride-1 conv the Winograd kernel covers on it (plan option `winograd`, default on;
-  // an explicit tile_cfg / split_bf16 / the training plan keep the direct halo kernels)
+  // every 3x3 stride-1 conv the Winograd kernel covers runs on it (plan option `winograd`, default on); an explicit
+  // tile_cfg / split_bf16 keep the direct halo kernels, and so do the training plan's block2 convs (train-mode dropout
+  // and the fused res_conv segment have no Winograd form)
   bool wino_ok(const ConvParams& c, size_t w, bool has_x2, bool has_drop) {
-    if (!P->winograd || train || P->tile_cfg != 0 || P->split_bf16 || has_x2 || has_drop) return false;
+    if (!P->winograd || P->tile_cfg != 0 || P->split_bf16 || has_x2 || has_drop) return false;
     if (c.ksize != 3 || c.stride != 1 || !P->derived_of.count(w)) return false;
     WinoGeom wg;
     return wino_geometry(c, &wg);
@@ -479,7 +480,8 @@ struct Builder {
     c.C0 = T[h1].C; c.B = B; c.Hs = T[h1].H; c.Ws = T[h1].W; c.stride = 1; c.ksize = 3;
     c.Ho = T[h1].H; c.Wo = T[h1].W; c.Cout = Cout;
     // the Winograd kernel has no second K-segment: res_conv runs as its own 1x1 GEMM and joins as a residual
-    if (wino_ok(c, w, false, false)) return false;
+    // (inference plan; the training plan's block2 conv carries dropout and stays on the halo kernel)
+    if (!train && wino_ok(c, w, false, false)) return false;
     int cfg = P->tile_cfg, ks = P->ksplit;
     conv_pick(c, cfg, ks);
     return cfg >= 5;
@@ -739,7 +741,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
   P->t_film_off = off; off += al((size_t)B * P->F * sizeof(float));
   P->t_scratch_off = off; P->t_scratch_bytes = bld.max_scratch; off += al(bld.max_scratch);
   // backward scratch
-  size_t max_dA = bld.max_dA, max_wt = bld.max_wt, max_slab = 0, max_part = 0, max_dwtmp = 0;
+  size_t max_dA = bld.max_dA, max_wt = bld.max_wt, max_slab = 0, max_part = 0, max_dwtmp = 0, max_wu = 0;
   size_t max_bscratch = 0;                    // split-K slabs of the data-gradient convs
   for (const Rec& r : P->recs) {
     ConvParams c;
@@ -759,6 +761,13 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       g.C0 = o.C; g.B = B; g.Hs = x0.H << r.ups; g.Ws = x0.W << r.ups; g.stride = 1; g.ksize = r.ksize;
       g.Ho = g.Hs; g.Wo = g.Ws; g.Cout = c.C0 + c.C1;
       max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
+      {   // the data gradient of a 3x3 conv runs on the Winograd kernel where it fits: its slabs and transformed filters
+        WinoGeom wg;
+        if (P->winograd && r.ksize == 3 && wino_geometry(g, &wg)) {
+          max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 11, 0));
+          max_wu = std::max(max_wu, wino_weight_floats(g.Cout, g.C0) * sizeof(float));
+        }
+      }
       if (r.has_q) {
         ConvParams q;
         memset(&q, 0, sizeof(q));
@@ -801,6 +810,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
   P->t_z_off = off; off += al(bld.max_z);
   P->t_dq_off = off; off += al(bld.max_dq);
   P->t_wt_off = off; off += al(max_wt);
+  P->t_wu_off = off; P->t_wu_bytes = max_wu; off += al(max_wu);
   P->t_slab_off = off; off += al(max_slab);
   P->t_part_off = off; off += al(max_part);
   P->t_gs_off = off; off += al((size_t)B * G * 2 * sizeof(double));
@@ -1145,8 +1155,16 @@ unsigned sr3_dropout_threshold(float drop_p, float* scale_out) {
 size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize, int tile_cfg, int ksplit) {
   ConvParams c;
   memset(&c, 0, sizeof(c));
-  c.B = B; c.Ho = Ho; c.Wo = Wo; c.Hs = Ho; c.Ws = Wo; c.stride = 1; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
-  return conv_splitk_bytes(c, tile_cfg, ksplit) + (tile_cfg == 11 ? wino_weight_floats(Cout, Cin) * sizeof(float) : 0);
+  c.B = B; c.Ho = Ho; c.Wo = Wo; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
+  if (tile_cfg == 11) {      // Winograd: the geometry (hence the split) needs the stride-1 input dims; + the derived filters
+    c.Hs = Ho; c.Ws = Wo; c.stride = 1;
+    return conv_splitk_bytes(c, tile_cfg, ksplit) + wino_weight_floats(Cout, Cin) * sizeof(float);
+  }
+  // the entry does not know the stride: take the larger of the stride-1 (halo kernel eligible) and the im2col sizing
+  const size_t a = conv_splitk_bytes(c, tile_cfg, ksplit);
+  c.Hs = Ho; c.Ws = Wo; c.stride = 1;
+  const size_t b = conv_splitk_bytes(c, tile_cfg, ksplit);
+  return a > b ? a : b;
 }
 int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, void* stream) {
   if (!x || !stat) { set_error("null argument"); return SR3_E_BADARG; }

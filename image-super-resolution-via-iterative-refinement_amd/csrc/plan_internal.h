@@ -128,6 +128,7 @@ struct sr3_plan {
   size_t t_dA_off = 0, t_z_off = 0, t_dq_off = 0, t_wt_off = 0, t_slab_off = 0, t_part_off = 0, t_gs_off = 0;
   size_t t_dfilm_off = 0, t_misc_off = 0, t_xnoisy_off = 0, t_eps_off = 0, t_geps_off = 0, t_inpad_off = 0, t_dwtmp_off = 0;
   size_t t_ws_bytes = 0, t_embscr_off = 0, t_a_off = 0;
+  size_t t_wu_off = 0, t_wu_bytes = 0;   // Winograd-transformed filters of the data-gradient conv being run
   std::vector<size_t> t_unproc_max;  // [ri]: max parameter end offset still unwritten before record ri-1 is processed
   int t_final_x = -1;                // tensor handle feeding the output Block
   size_t t_final_ss = 0, t_final_mr = 0;

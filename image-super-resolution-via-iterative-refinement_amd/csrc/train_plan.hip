@@ -41,6 +41,17 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   memset(&c, 0, sizeof(c));
   c.src0 = g; c.C0 = Cg; c.B = X.B; c.Hs = H; c.Ws = W; c.stride = 1; c.ksize = ksize; c.Ho = H; c.Wo = W;
   c.Cout = Cin; c.w = wt; c.out = dA; c.ksplit = 1;
+  // 3x3: Winograd F(2x2,3x3) on the flipped-transposed filters where the geometry fits (the data gradient has neither a
+  // prologue nor dropout, so every 3x3 stride-1 / zero-inserted stride-2 layer with H, W multiples of 16 qualifies)
+  WinoGeom wg;
+  if (X.P->winograd && ksize == 3 && wino_geometry(c, &wg) &&
+      wino_weight_floats(Cin, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
+    float* wu = X.at<float>(X.P->t_wu_off);
+    rc = wino_transform_weights(wt, Cin, Cg, wu, X.st);
+    if (rc) return rc;
+    c.wino_u = wu;
+    return conv_forward(c, 11, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
+  }
   return conv_forward(c, 0, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
 }
 

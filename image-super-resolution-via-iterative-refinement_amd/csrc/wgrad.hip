@@ -289,9 +289,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad9(const float* __restrict_
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ slabs, int msplit, size_t n4,
                                                        float* __restrict__ dw) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(slabs + i * 4);
-    for (int s = 1; s < msplit; ++s) v += *reinterpret_cast<const f32x4*>(slabs + ((size_t)s * n4 + i) * 4);
-    *reinterpret_cast<f32x4*>(dw + i * 4) = v;
+    // double accumulation: a batch can hold samples whose gradient terms are orders of magnitude larger than the
+    // others' (noise levels near 0); summing their slabs with the rest in fp32 costs the small ones their low bits
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int s = 0; s < msplit; ++s) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + ((size_t)s * n4 + i) * 4);
+      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    const f32x4 r = {(float)a0, (float)a1, (float)a2, (float)a3};
+    *reinterpret_cast<f32x4*>(dw + i * 4) = r;
   }
 }
 

@@ -188,6 +188,7 @@ class EngineUNet(nn.Module):
     # ---- training step (forward + backward inside the engine) ------------------------------------
     def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, drop_seed=None):
         import ctypes as C
+        self.ensure_derived()          # the train plan's block1 / Upsample convs run on the Winograd kernel
         p_drop = self.dropout if self.training else 0.0
         if drop_seed is None:          # a fresh mask every step, drawn from torch's CPU generator
             drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0

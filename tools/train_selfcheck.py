@@ -20,6 +20,8 @@ def main():
     ap.add_argument('--config', default='sr3_16_128')
     ap.add_argument('--opt', action='append', default=[])
     ap.add_argument('--top', type=int, default=8)
+    ap.add_argument('--offset', type=int, default=0)
+    ap.add_argument('--dup', action='store_true', help='the batch is --batch/--sub copies of the first --sub samples')
     a = ap.parse_args()
     from test_gpu_bench_configs import _build
     netG, sd, desc, opt, c = _build(a.config, phase='train', seed=17, dropout=0.0)
@@ -27,10 +29,17 @@ def main():
     d = torch.device('cuda:0')
     B, S = a.batch, c['size']
     g = torch.Generator().manual_seed(8)
-    hr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(d)
-    sr = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(d)
-    z = torch.randn(B, 3, S, S, generator=g).to(d)
-    gamma = torch.rand(B, generator=g) * 0.9 + 0.05
+    NB = max(64, B + a.offset)
+    o = a.offset
+    hr = (torch.rand(NB, 3, S, S, generator=g) * 2 - 1)[o:o + B].to(d)
+    sr = (torch.rand(NB, 3, S, S, generator=g) * 2 - 1)[o:o + B].to(d)
+    z = torch.randn(NB, 3, S, S, generator=g)[o:o + B].to(d)
+    gamma = (torch.rand(NB, generator=g) * 0.9 + 0.05)[o:o + B]
+    print('gamma', [round(float(x), 3) for x in gamma])
+    if a.dup:
+        rep = B // a.sub
+        hr, sr, z = [t[:a.sub].repeat(rep, 1, 1, 1) for t in (hr, sr, z)]
+        gamma = gamma[:a.sub].repeat(rep)
     un = netG.denoise_fn
     ref = None
     for lo in range(0, B, a.sub):
