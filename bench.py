@@ -255,11 +255,13 @@ def reference_cpu_baseline(ref, cfg_name, netG, par, cores, budget_s, train_batc
     return json.loads(r.stdout.decode().strip().splitlines()[-1])
 
 
-def torch_rocm_baseline(cfg_name, netG, par, dev, steps=5, train_batch=4):
+def torch_rocm_baseline(cfg_name, netG, par, dev, steps=5, train_batch=None):
     """The same oracle ops on the GPU through stock PyTorch-ROCm (MIOpen convolutions, rocBLAS GEMMs, eager): the
     'unmodified reference on this node' number for sampling and training.  Also a parity cross-check of the engine."""
     O, desc, tab, sd, torch = oracle_tools(cfg_name, netG)
     B = par['x'].shape[0]
+    if train_batch is None:
+        train_batch = CONFIGS[cfg_name]['train_batch']      # the batch the `train` leg is quoted on
     sdd = {k: v.to(dev) for k, v in sd.items()}
     x, z = par['x'].to(dev), par['z'].to(dev)
     cond = None if par['cond'] is None else par['cond'].to(dev)
@@ -332,7 +334,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
              155: 'k_conv3x3_halo<2,2,false,false,1,2>', 157: 'k_conv3x3_halo<2,2,true,false,1,2>',
              156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
              355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
-             455: 'k_conv3x3_wino<1>'}
+             455: 'k_conv3x3_wino'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -344,7 +346,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
               for k, v in sorted(agg.items())}
     traffic = None
     counters = None
-    kname = 'void sr3::' + names[dom].replace(',', ', ') if dom == 455 else 'sr3::' + names[dom].replace(',', ', ')
+    kname = 'sr3::' + names[dom].replace(',', ', ')
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
         with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_hbm_traffic.json')) as f:
             traffic = json.load(f)[kname]['hbm_bytes_per_launch']

@@ -360,13 +360,17 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   const int ftile = (tid & 127) >> 3, fcq = tid & 7;
   const int T = g.tiles_h * g.tiles_w;                             // statistics partials per image
   const int tix = th_i * g.tiles_w + tw_i;
+  double s1[2][4], s2[2][4];                                       // this thread's channel quad of either 32-channel block
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[a][k] = 0.0; s2[a][k] = 0.0; }
 #pragma unroll
   for (int nblk = 0; nblk < 2; ++nblk) {
     const int n = cb * WBN + nblk * 32 + fcq * 4;
     const bool nok = n < p.Cout;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-    double tot1 = 0.0, tot2 = 0.0;                  // writer threads: running sums over the two tile blocks
 #pragma unroll
     for (int mblk = 0; mblk < 2; ++mblk) {
       f32x16 p0, p1;
@@ -387,11 +391,8 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         e1[row * WLDT + (lane & 31)] = p1[r];
       }
       __syncthreads();
-      double s1[2][4], s2[2][4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s1[e][k] = 0.0; s2[e][k] = 0.0; }
         const int trow = ftile + 16 * e;                 // tile row inside this 32-tile block
         auto rd = [&](int i, int hh) {
           return *reinterpret_cast<const f32x4*>(exch + (((i * 2 + hh) * 2 + fq) * 32 + trow) * WLDT + fcq * 4);
@@ -412,42 +413,35 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
             }
             if (stats) {
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { const double dv = (double)v[k]; s1[e][k] += dv; s2[e][k] += dv * dv; }
+              for (int k = 0; k < 4; ++k) { const double dv = (double)v[k]; s1[nblk][k] += dv; s2[nblk][k] += dv * dv; }
             }
           }
           *reinterpret_cast<f32x4*>(dst + pix * p.Cout + n) = v;
         }
       }
       __syncthreads();                                  // every read of the exchange block is complete
-      if (stats) {
-        // Per-channel sums of this block's outputs (one image per tile), reduced in a fixed order: every thread parks its
-        // two accumulator sets in the (now free) exchange region, then one thread per (channel, tile half) walks the 64
-        // threads that share its channel quad; the two halves and the two tile blocks are folded by the writer.
+    }
+  }
+  if (stats) {
+    // Per-channel sums of this tile's outputs (one image per tile), reduced once, in a fixed order: every thread parks the
+    // sums of its two channel quads (one per 32-channel block) in the now free exchange region, then one thread per
+    // (channel, sum) walks the 64 threads (4 sub-pixels x 16 tile rows) that share its channel quad.
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+    for (int nb2 = 0; nb2 < 2; ++nb2)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { part[(tid * 2 + e) * 8 + k] = s1[e][k]; part[(tid * 2 + e) * 8 + 4 + k] = s2[e][k]; }
-        __syncthreads();
-        if (tid < 64) {
-          const int c = tid & 31, e = tid >> 5;
-          double a1 = 0.0, a2 = 0.0;
-#pragma unroll 4
-          for (int src = 0; src < 64; ++src) {
-            const int t = (src >> 4) * 128 + (src & 15) * 8 + (c >> 2);
-            a1 += part[(t * 2 + e) * 8 + (c & 3)];
-            a2 += part[(t * 2 + e) * 8 + 4 + (c & 3)];
-          }
-          a1 += __shfl_xor(a1, 32);                     // lanes 0-31: e = 0, lanes 32-63: e = 1
-          a2 += __shfl_xor(a2, 32);
-          tot1 += a1; tot2 += a2;
-          const int nn = cb * WBN + nblk * 32 + c;
-          if (mblk == 1 && e == 0 && nn < p.Cout) {
-            double* o = p.ostat + (((size_t)b0 * T + tix) * p.Cout + nn) * 2;
-            o[0] = tot1; o[1] = tot2;
-          }
-        }
-        __syncthreads();                                // the parked sums are consumed before the next block is written
+      for (int k = 0; k < 4; ++k) { part[(tid * 2 + nb2) * 8 + k] = s1[nb2][k]; part[(tid * 2 + nb2) * 8 + 4 + k] = s2[nb2][k]; }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;              // channel of the 64-wide block, 0 = sum | 1 = sum of squares
+      const int nb2 = c >> 5, cq = (c & 31) >> 2, k = c & 3;
+      double a = 0.0;
+#pragma unroll 8
+      for (int src = 0; src < 64; ++src) {
+        const int t = (src >> 4) * 128 + (src & 15) * 8 + cq;
+        a += part[(t * 2 + nb2) * 8 + which * 4 + k];
       }
+      const int nn = cb * WBN + c;
+      if (nn < p.Cout) p.ostat[(((size_t)b0 * T + tix) * p.Cout + nn) * 2 + which] = a;
     }
   }
 }

@@ -336,6 +336,8 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
     }
   }
+  if (tile_cfg == 0 && p.ksize == 1) tile_cfg = 3;   // 1x1 convs: the 64x64 tile measured fastest on every layer shape of the
+                                                     // BASELINE networks (76-81 vs 58-64 TF at 16x16, 78 vs 69 at 128x128)
   if (tile_cfg == 0) {
     // im2col kernel: largest tile that still gives >= ~2 workgroups per CU
     const int order_wide[3] = {1, 2, 3};

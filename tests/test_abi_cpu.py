@@ -158,15 +158,16 @@ def test_plan_launch_list_no_gpu():
     gets, what is fused, and that the opt-in split option only re-targets halo-tile convolutions."""
     from sr3_hip import engine as E
     p = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
-    # default inference plan: every 3x3 stride-1 conv on the Winograd F(2x2,3x3) kernel (tile 11); the 18 res_convs
-    # of the channel-changing blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
+    # default inference plan: every 3x3 stride-1 conv on a map of 16x16 or larger on the Winograd F(2x2,3x3) kernel
+    # (tile 11); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
     wops = p.op_list(16)
-    assert len(wops) == p.num_ops(16) == 169
+    assert len(wops) == p.num_ops(16) == 166
     wconvs = [o for o in wops if o['kind'] == 50]
-    for o in wconvs:
-        assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1), o
-        assert not o['fused_res_conv_cin']
-    assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 18
+    for o in wconvs:      # 8x8 maps keep the direct halo kernel (and with it the fused res_conv segment)
+        assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
+        assert not o['fused_res_conv_cin'] or (o['tile_cfg'] == 5 and o['h_out'] == 8)
+    assert sum(1 for o in wconvs if o['fused_res_conv_cin']) == 3
+    assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 15
     assert abs(sum(o['flops'] for o in wops) / 16 / 1e9 - 92.18) < 0.05       # algorithmic FLOPs do not change
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) > 0
     # the direct kernels (plan option winograd = 0; also what the training plan and an explicit tile_cfg use)

@@ -262,20 +262,25 @@ def unet_time_split(B, nsplit, out_path):
 def config_times(out_path):
     """Forward timing (hipGraph) of the other BASELINE.json configurations."""
     d = torch.device('cuda:0')
-    cfgs = [('C2 sr3_16_128 B16', 'sr3', 6, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128, 16, 3),
-            ('C4 sr3_64_512 B4', 'sr3', 6, 64, 16, [1, 2, 4, 8, 16], [], 1, 512, 4, 3),
-            ('C5 ddpm_128 B32', 'ddpm', 3, 64, 32, [1, 1, 2, 2, 4, 4], [16], 2, 128, 32, 0),
-            ('C2 sr3_16_128 B1', 'sr3', 6, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128, 1, 3)]
-    for (name, var, inc, inner, groups, mults, attn, rb, size, B, cc) in cfgs:
-        plan = E.Plan(var, inc, 3, inner, groups, mults, attn, rb, size)
-        arena = torch.randn(plan.param_floats, device=d) * 0.02
-        freq = plan.default_freq().to(d)
-        ws = E.Workspace()
-        x = torch.randn(B, inc - cc, size, size, device=d)
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    import model.networks as networks
+    for (name, cfg, B) in [('C2 sr3_16_128 B16', 'sr3_16_128', 16), ('C4 sr3_64_512 B4', 'sr3_64_512', 4),
+                           ('C5 ddpm_128 B32', 'ddpm_128', 32), ('C2 sr3_16_128 B1', 'sr3_16_128', 1)]:
+        c = bench.CONFIGS[cfg]
+        torch.manual_seed(0)
+        netG = networks.define_G(bench.config_opt(cfg)).to(d)
+        un = netG.denoise_fn
+        plan = un.plan
+        size, cc = c['size'], 3 if c['conditional'] else 0
+        x = torch.randn(B, 3, size, size, device=d)
         cond = torch.randn(B, cc, size, size, device=d) if cc else None
         out = torch.empty(B, 3, size, size, device=d)
-        kw = dict(noise_level=torch.full((B,), 0.5, device=d)) if var == 'sr3' else dict(timestep=torch.full((B,), 777, device=d, dtype=torch.long))
-        fn = lambda: E.unet_forward(plan, arena, freq, ws, x, cond=cond, out=out, **kw)
+        tm = torch.full((B,), 0.5, device=d) if c['which'] == 'sr3' else torch.full((B,), 777, device=d, dtype=torch.long)
+        fn = lambda: un(x, tm, cond=cond, out=out)
         fn()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -289,7 +294,7 @@ def config_times(out_path):
         with open(out_path, 'a') as f:
             f.write(json.dumps(rec) + '\n')
         print(rec, flush=True)
-        del arena, ws, x, out
+        del netG, x, out
 
 
 def train_time(B, out_path, iters=5, config='sr3_16_128'):
@@ -301,20 +306,9 @@ def train_time(B, out_path, iters=5, config='sr3_16_128'):
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     import model as Model
-    opt = bench.sr3_16_128_opt()
-    opt['phase'] = 'train'
+    opt = bench.config_opt(config, phase='train')
     opt['model']['unet']['dropout'] = 0
-    S = 128
-    if config == 'ddpm_128':          # config/sample_ddpm_128.json
-        opt['model']['which_model_G'] = 'ddpm'
-        opt['model']['unet'].update(in_channel=3, channel_multiplier=[1, 1, 2, 2, 4, 4])
-        opt['model']['diffusion']['conditional'] = False
-        for ph in ('train', 'val'):
-            opt['model']['beta_schedule'][ph].update(linear_start=1e-4, linear_end=2e-2)
-    elif config == 'sr3_64_512':      # config/sr_sr3_64_512.json
-        S = 512
-        opt['model']['unet'].update(channel_multiplier=[1, 2, 4, 8, 16], attn_res=[], res_blocks=1, norm_groups=16)
-        opt['model']['diffusion']['image_size'] = 512
+    S = bench.CONFIGS[config]['size']
     torch.manual_seed(0)
     m = Model.create_model(opt)
     d = torch.device('cuda:0')
