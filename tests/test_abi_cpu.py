@@ -161,19 +161,18 @@ def test_plan_launch_list_no_gpu():
     # default inference plan: every 3x3 stride-1 conv on a map of 16x16 or larger on the Winograd F(2x2,3x3) kernel
     # (tile 11); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
     wops = p.op_list(16)
-    assert len(wops) == p.num_ops(16) == 166
+    assert len(wops) == p.num_ops(16) == 169
     wconvs = [o for o in wops if o['kind'] == 50]
-    for o in wconvs:      # 8x8 maps keep the direct halo kernel (and with it the fused res_conv segment)
+    for o in wconvs:      # 8x8 maps keep the direct halo kernel (split-K, so without the fused res_conv segment)
         assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
-        assert not o['fused_res_conv_cin'] or (o['tile_cfg'] == 5 and o['h_out'] == 8)
-    assert sum(1 for o in wconvs if o['fused_res_conv_cin']) == 3
-    assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 15
+        assert not o['fused_res_conv_cin']
+    assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 18
     assert abs(sum(o['flops'] for o in wops) / 16 / 1e9 - 92.18) < 0.05       # algorithmic FLOPs do not change
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) > 0
     # the direct kernels (plan option winograd = 0; also what the training plan and an explicit tile_cfg use)
     p.set_option('winograd', 0)
     ops = p.op_list(16)
-    assert len(ops) == p.num_ops(16) == 151
+    assert len(ops) == p.num_ops(16) == 151 + 11
     convs = [o for o in ops if o['kind'] == 50]
     assert sum(1 for o in ops if o['kind'] == 60) == 6 and sum(1 for o in ops if o['kind'] == 40) == 61
     # every 3x3 stride-1 conv runs on the halo-tile kernel; 1x1 and stride-2 convs on the im2col kernel
@@ -182,9 +181,11 @@ def test_plan_launch_list_no_gpu():
         assert halo == (o['ksize'] == 3 and o['stride'] == 1), o
         if o['fused_res_conv_cin']:
             assert halo and not o['upsample']
-    # 18 ResnetBlocks change their channel count: their 1x1 res_conv rides inside block2's launch
-    assert sum(1 for o in convs if o['fused_res_conv_cin']) == 18
-    assert sum(1 for o in convs if o['ksize'] == 1) == 12              # qkv + out of the 6 attention blocks only
+    # 18 ResnetBlocks change their channel count: where block2's conv runs unsplit (the 128x128 and 64x64 levels) their
+    # 1x1 res_conv rides inside its launch; under split-K (32x32 and below at batch 16) it stays a 1x1 GEMM of its own
+    assert sum(1 for o in convs if o['fused_res_conv_cin']) == 7
+    assert all(o['ksplit'] == 1 for o in convs if o['fused_res_conv_cin'])
+    assert sum(1 for o in convs if o['ksize'] == 1) == 12 + 11         # qkv + out of the 6 attention blocks + 11 res_convs
     # Cout <= 64 layers: 256x64 tile; Cout > 64 layers whose 256x128 tiling still gives one workgroup per CU (256): the
     # 8-wave tile; the remaining small-M layers: 128x128 + split-K
     for o in convs:

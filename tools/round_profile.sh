@@ -24,8 +24,14 @@ python tools/pmc_sq.py $OUT/sq $OUT/$TAG >> $OUT/pmc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python tools/gpu_probe.py --train 64 > $OUT/train_probe.log 2>&1
 python bench.py --config sr3_64_512 --steps 200 --warmup 3 --train-steps 3 --no-split-leg --no-torch-baseline > $OUT/bench_sr3_64_512.json 2> $OUT/bench_sr3_64_512.err
 python bench.py --config ddpm_128 --steps 400 --warmup 5 --train-steps 5 --no-split-leg --no-torch-baseline > $OUT/bench_ddpm_128.json 2> $OUT/bench_ddpm_128.err
+# the multi-rank entry paths on this 1-GPU box: collective path forced on one rank, the launcher form the driver uses, and the
+# refusal of --gpus 2 with one visible device
+D="--steps 20 --warmup 3 --train-steps 2 --no-cpu-baseline --no-torch-baseline --no-roofline"
+SR3_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $D > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; echo "force_dist rc=$?"
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 $D > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err; echo "torchrun rc=$?"
+python bench.py --gpus 2 $D > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; echo "gpus2 rc=$? (2 = refused, expected on a 1-GPU box)"
 grep -h "train_step" $OUT/train_probe.log | cut -c1-260
-for f in $OUT/bench.json $OUT/bench_sr3_64_512.json $OUT/bench_ddpm_128.json; do cut -c1-260 $f; echo; done
+for f in $OUT/bench.json $OUT/bench_sr3_64_512.json $OUT/bench_ddpm_128.json $OUT/bench_force_dist.json $OUT/bench_torchrun1.json; do cut -c1-260 $f; echo; done
 # keep the merged-back payload small: the per-dispatch traces are not needed, the statistics and counter summaries are
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +4M -delete
