@@ -10,6 +10,11 @@
 // Prologue (GroupNorm affine for qkv, none for res_conv / out), concat seam, epilogue (bias, FiLM, residual, 16-byte NHWC
 // stores, split-K slabs) as in the other conv kernels; GroupNorm statistics of the output are left to the stand-alone
 // pass / the split-K reduce, exactly as for the im2col kernel.
+//
+// STATUS (round 2): correct (tests/test_gpu_ops.py::test_conv with tile 12, full-network parity with the option on) but
+// NOT faster on this network: 68 TF over the 30 1x1 launches of a C2 forward against 72 TF for the im2col kernel's 64x64
+// tile, plus more split-K reduces (the 128x128 tile leaves the 16x16 layers with 128 workgroups) -- only 32 MFMAs per
+// wave between barriers and K of 64..512 leave it prologue / epilogue bound.  Plan option "gemm1x1", default 0.
 #include <stdlib.h>
 
 #include "sr3_common.h"

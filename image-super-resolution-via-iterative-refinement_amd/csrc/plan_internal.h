@@ -101,7 +101,8 @@ struct sr3_plan {
   int fin_cin = 0, out_ch = 0;
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
-  int gemm1x1 = 1;           // 1x1 convs (res_conv, attention qkv / out) on the fragment-major-weights GEMM kernel (gemm1x1.hip)
+  int gemm1x1 = 0;           // opt-in experiment: 1x1 convs on the fragment-major-weights GEMM kernel (gemm1x1.hip); measured
+                             // 68 TF vs 72 TF for the im2col kernel's 64x64 tile on this network's layers, so off by default
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };

@@ -161,7 +161,7 @@ def test_plan_launch_list_no_gpu():
     # default inference plan: every 3x3 stride-1 conv on a map of 16x16 or larger on the Winograd F(2x2,3x3) kernel
     # (tile 11); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
     wops = p.op_list(16)
-    assert len(wops) == p.num_ops(16) == 165
+    assert len(wops) == p.num_ops(16) == 169
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:      # 8x8 maps keep the direct halo kernel (split-K, so without the fused res_conv segment)
         assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
@@ -172,14 +172,14 @@ def test_plan_launch_list_no_gpu():
     # the direct kernels (plan option winograd = 0; also what the training plan and an explicit tile_cfg use)
     p.set_option('winograd', 0)
     ops = p.op_list(16)
-    assert len(ops) == p.num_ops(16) == 151 + 11 - 4      # 4 attention `out` convs run split-K: their statistics come from the reduce
+    assert len(ops) == p.num_ops(16) == 151 + 11
     convs = [o for o in ops if o['kind'] == 50]
     assert sum(1 for o in ops if o['kind'] == 60) == 6 and sum(1 for o in ops if o['kind'] == 40) == 61
     # every 3x3 stride-1 conv runs on the halo-tile kernel; 1x1 and stride-2 convs on the im2col kernel
     for o in convs:
         halo = 5 <= o['tile_cfg'] <= 10
         assert halo == (o['ksize'] == 3 and o['stride'] == 1), o
-        assert (o['tile_cfg'] == 12) == (o['ksize'] == 1), o          # 1x1 convs: the fragment-major-weights GEMM kernel
+        assert o['ksize'] != 1 or o['tile_cfg'] == 3, o               # 1x1 convs: the im2col kernel's 64x64 tile
         if o['fused_res_conv_cin']:
             assert halo and not o['upsample']
     # 18 ResnetBlocks change their channel count: where block2's conv runs unsplit (the 128x128 and 64x64 levels) their
@@ -212,6 +212,10 @@ def test_plan_launch_list_no_gpu():
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('split_bf16', 0)
     assert p.op_list(16) == ops
+    # opt-in experiment: the fragment-major-weights 1x1 GEMM kernel (tile 12) takes over every 1x1 conv
+    p.set_option('gemm1x1', 1)
+    assert all((o['tile_cfg'] == 12) == (o['ksize'] == 1) for o in p.op_list(16) if o['kind'] == 50)
+    p.set_option('gemm1x1', 0)
     # batch 1: everything is small-M
     assert all(o['tile_cfg'] != 9 or o['h_out'] >= 128 for o in p.op_list(1) if o['kind'] == 50)
 
