@@ -229,3 +229,67 @@ def test_prepare_data_triplets_match_the_reference_pipeline(tmp_path):
     assert len(ds) == 4 and tuple(ds[0]['SR'].shape) == (128, 128, 3)
     lr_b, hr_b, sr_b = P.resize_multiple(Image.open(str(src / '0.png')).convert('RGB'), (16, 128), Image.BICUBIC, lmdb_save=True)
     assert np.array_equal(np.asarray(Image.open(__import__('io').BytesIO(sr_b))), np.asarray(Image.open(os.path.join(out, 'sr_16_128', '00000.png'))))
+
+
+def test_infer_py_call_sequence(tmp_path):
+    """The call sequence of the reference's infer.py (lines 44-90) through the drop-in packages only: create_dataset /
+    create_dataloader('val') on PNG triplets -> Model.create_model -> set_new_noise_schedule(val) -> per image
+    feed_data / test(continous=True) / get_current_visuals(need_LR=False) -> Metrics.tensor2img / save_img of HR, INF, the
+    SR process grid and the final SR -- and the final image equals the oracle's reverse loop fed the same draws."""
+    import core.metrics as M
+    import data as Data
+    import model as Model
+    from PIL import Image
+    from helpers import DESCS, SCHEDS, load_golden, opt_for
+    from oracle import sr3_oracle as SO
+    root = str(tmp_path / 'ds')
+    _write_triplets(root, 2, l=4, r=16)
+    dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
+    val_set = Data.create_dataset(dopt, 'val')
+    val_loader = Data.create_dataloader(val_set, dopt, 'val')
+    opt = opt_for('sr3_tiny', phase='val', gpu=True)
+    diffusion = Model.create_model(opt)
+    _, sd = load_golden('sr3_tiny')
+    diffusion.netG.load_state_dict(sd, strict=True)
+    diffusion.netG.show_progress = False
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+    result_path = str(tmp_path / 'results')
+    os.makedirs(result_path, exist_ok=True)
+    T = SCHEDS['sr3_tiny']['n_timestep']
+    tab = SO.schedule_tables(SCHEDS['sr3_tiny'])
+    idx = 0
+    for _, val_data in enumerate(val_loader):
+        idx += 1
+        diffusion.feed_data(val_data)
+        torch.manual_seed(100 + idx)
+        diffusion.test(continous=True)
+        visuals = diffusion.get_current_visuals(need_LR=False)
+        hr_img = M.tensor2img(visuals['HR'])
+        fake_img = M.tensor2img(visuals['INF'])
+        sr_img = M.tensor2img(visuals['SR'])
+        last = M.tensor2img(visuals['SR'][-1])
+        M.save_img(sr_img, '{}/{}_{}_sr_process.png'.format(result_path, 0, idx))
+        M.save_img(last, '{}/{}_{}_sr.png'.format(result_path, 0, idx))
+        M.save_img(hr_img, '{}/{}_{}_hr.png'.format(result_path, 0, idx))
+        M.save_img(fake_img, '{}/{}_{}_inf.png'.format(result_path, 0, idx))
+        n_snap = sum(1 for i in range(T) if i % (1 | (T // 10)) == 0)
+        assert tuple(visuals['SR'].shape) == (n_snap + 1, 3, 16, 16) and visuals['SR'].device.type == 'cpu'
+        assert hr_img.shape == (16, 16, 3) and hr_img.dtype == np.uint8 and last.shape == (16, 16, 3)
+        # the saved HR / INF are the dataset's PNGs again (uint8 -> [-1, 1] -> uint8 is the identity)
+        k = idx - 1
+        assert np.array_equal(np.asarray(Image.open('{}/{}_{}_hr.png'.format(result_path, 0, idx)).convert('RGB')),
+                              np.asarray(Image.open(os.path.join(root, 'hr_16', '%05d.png' % k)).convert('RGB')))
+        assert np.array_equal(fake_img, np.asarray(Image.open(os.path.join(root, 'sr_4_16', '%05d.png' % k)).convert('RGB')))
+        # same chain on the CPU oracle: replay the device RNG draws (x_T, then one z per step) of this seed
+        torch.manual_seed(100 + idx)
+        d = torch.device('cuda:0')
+        x_T = torch.randn((1, 3, 16, 16), device=d)
+        zs = [torch.empty((1, 3, 16, 16), device=d).normal_() for _ in range(T)]      # the loop draws at i = T-1 .. 0
+        zseq = torch.stack(list(reversed(zs))).cpu()                                    # zs[i] = noise consumed at step i
+        with torch.no_grad():
+            ref = SO.p_sample_loop(sd, DESCS['sr3_tiny'], tab, val_data['SR'].cpu(), x_T.cpu(), zseq, conditional=True,
+                                   continous=True)
+        assert tuple(ref.shape) == tuple(visuals['SR'].shape)
+        err = (visuals['SR'] - ref).abs().max().item()
+        assert err <= 1e-4, err
+    assert idx == 2 and len(os.listdir(result_path)) == 8
