@@ -133,3 +133,28 @@ def test_cosine_schedule_buffers_match_reference():
             assert np.array_equal(np.asarray(netG.sqrt_alphas_cumprod_prev), g['buf/cosine50/' + k])
         else:
             assert np.array_equal(sdn[k].numpy(), g['buf/cosine50/' + k]), k
+
+
+def test_winograd_f2x3_fp32_is_in_the_direct_convolutions_error_class():
+    """The engine's 3x3 convolutions run as Winograd F(2x2,3x3) in fp32 (csrc/conv3x3_wino.hip).  CPU restatement of that
+    arithmetic (transforms B^T d B, G g G^T, A^T m A with their 0 / +-1 / +-1/2 coefficients, everything fp32) on one layer
+    against float64: its error must stay within a small factor of the plain fp32 convolution's -- the numerical basis for
+    keeping the stated tolerance unchanged (tools/winograd_numerics.py runs the same emulation over the whole UNet)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+    p = F.pad(x, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)                  # B, C, H/2, W/2, 4, 4 patches, stride 2
+    V = torch.einsum('ir,bcyxrs,js->bcyxij', BT, p, BT)
+    U = torch.einsum('ir,ocrs,js->ocij', G, w, G)
+    M = torch.einsum('bcyxij,ocij->boyxij', V, U)
+    Y = torch.einsum('pi,boyxij,qj->boyxpq', AT, M, AT).permute(0, 1, 2, 4, 3, 5).reshape(2, 96, 32, 32)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    direct = F.conv2d(x, w, padding=1)
+    e_w = (Y.double() - ref).abs().max().item()
+    e_d = (direct.double() - ref).abs().max().item()
+    assert Y.dtype == torch.float32 and e_w <= 4.0 * e_d + 1e-7 * ref.abs().max().item(), (e_w, e_d)
+    assert e_w <= 2e-5 * max(1.0, ref.abs().max().item())
