@@ -111,3 +111,30 @@ def test_reference_cpu_baseline_tool_runs(tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-800:]
     rec = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert rec['kind'] == 'reference' and rec['value'] > 0 and rec['train']['value'] > 0, rec
+
+
+@needs_ref
+@pytest.mark.parametrize('name', ['sr3_16_128', 'sr3_64_512', 'ddpm_128'])
+def test_bench_configs_are_the_reference_json_configs(name):
+    """bench.py's CONFIGS / config_opt restate the `model` subtree of the reference's JSON files (comments stripped as
+    core/logger.py:21-33 does): same network, same schedules, same image size -- so the bench line measures the
+    configuration BASELINE.json names."""
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    c = bench.CONFIGS[name]
+    with open(os.path.join(REF, c['ref_json'])) as f:
+        txt = '\n'.join(line.split('//')[0] for line in f)
+    ref = json.loads(txt)['model']
+    got = bench.config_opt(name)['model']
+    assert got['which_model_G'] == ref['which_model_G']
+    for k, v in ref['unet'].items():
+        assert got['unet'].get(k, 32 if k == 'norm_groups' else None) == v, (k, v)
+    assert set(got['unet']) <= set(ref['unet']) | {'norm_groups'}
+    for ph in ('train', 'val'):
+        for k in ('schedule', 'n_timestep', 'linear_start', 'linear_end'):
+            assert got['beta_schedule'][ph][k] == ref['beta_schedule'][ph][k], (ph, k)
+    assert got['diffusion']['image_size'] == ref['diffusion']['image_size'] == c['size']
+    assert got['diffusion']['conditional'] == ref['diffusion']['conditional'] == c['conditional']
+    full = json.loads(txt)
+    assert abs(full['train']['optimizer']['lr'] - c['lr']) < 1e-12
