@@ -69,6 +69,7 @@ def _rank_main(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)          # a wedged collective must fail this test, not hang the suite
 @pytest.mark.parametrize('world', [1, 2])
 def test_dp_training_step_matches_oracle_on_the_global_batch(world):
     if torch.cuda.device_count() < world:
