@@ -164,3 +164,18 @@ def test_single_process_loader_unchanged():
     import data as Data
     dl = Data.create_dataloader(_IndexDataset(10), dict(batch_size=4, use_shuffle=False, num_workers=0), 'train')
     assert [b['Index'].tolist() for b in dl] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def test_bench_refuses_inconsistent_rank_counts():
+    """bench.py --gpus N: it launches the ranks itself only when N devices are visible, and under a launcher it refuses a
+    WORLD_SIZE that differs from --gpus -- it never prints a line whose n_gpus is not the number of ranks that ran."""
+    import subprocess
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    if torch.cuda.device_count() < 2:
+        assert r.returncode == 2 and b'refusing' in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-300:])
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0'),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and b'WORLD_SIZE=4' in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-300:])
