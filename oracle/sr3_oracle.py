@@ -1,9 +1,11 @@
 """CPU oracle for the SR3 / DDPM iterative-refinement hot path.
 
 TEST INFRASTRUCTURE ONLY.  This file is the checker, never the product: only
-``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
-import it.  The shipped path (``image-super-resolution-via-iterative-refinement_amd``)
-must never route through it.
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s baseline / parity legs
+(``cpu_baseline``, the ``parity`` check of the timed graph, and ``torch_rocm_baseline``,
+which runs these same torch ops on ``cuda`` as the "stock PyTorch-ROCm" number) plus the
+diagnostic probes under ``tools/`` may import it.  The shipped path
+(``image-super-resolution-via-iterative-refinement_amd``) must never route through it.
 
 It is a functional fp32 restatement (torch CPU ops on plain tensors, driven by a
 reference-format ``state_dict``) of the reference algorithm; every function cites
