@@ -63,6 +63,9 @@ def tensor2img(tensor, out_type=np.uint8, min_max=(-1, 1)):
 def save_img(img, img_path, mode='RGB'):
     """core/metrics.py:37-39 writes the RGB array (cv2.imwrite of the BGR-swapped copy); PIL writes it as is."""
     from PIL import Image
+    from sr3_hip.dist import is_primary
+    if not is_primary():     # data parallel: every rank holds the same validation images (ValWave); rank 0 writes them
+        return
     Image.fromarray(np.ascontiguousarray(img)).save(img_path)
 
 

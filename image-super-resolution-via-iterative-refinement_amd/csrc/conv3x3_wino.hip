@@ -129,6 +129,10 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// DBG (profiling ablations only, env SR3_WINO_DBG; 0 in production): 1 skip the MFMAs, 2 skip the GroupNorm / SiLU arithmetic of
+// the staging step, 4 skip the input transforms, 8 skip the epilogue, 16 skip the U loads of the loop, 32 skip the raw staging
+// of the loop (global loads + activation + LDS stores)
+template <int DBG>
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
   extern __shared__ f32x4 smem_v[];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       const int hp = lrow + (WNT / 4) * j;
       if (hp < WHP) {
         f32x4 v = rh[j];
-        if (p.act != 0) {
+        if (p.act != 0 && !(DBG & 2)) {
           v.x = fmaf(v.x, ssa.x, ssa.y);
           v.y = fmaf(v.y, ssa.z, ssa.w);
           v.z = fmaf(v.z, ssb.x, ssb.y);
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // the transform of one channel quad, split so that its six LDS reads can be in flight across an MFMA block:
   //   t_load issues the reads, t_finish does the row pass (3 FMAs), the column pass (2 adds) and the two LDS writes
   auto t_load = [&](const float* rawbuf, int cq, f32x4 (&da)[3], f32x4 (&db)[3]) {
+    if (DBG & 4) return;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + s * WRS + cq * 4);
@@ -238,6 +243,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     }
   };
   auto t_finish = [&](int cq, const f32x4 (&da)[3], const f32x4 (&db)[3]) {
+    if (DBG & 4) return;
     f32x4 t[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) t[s] = da[s] + db[s] * rsgn;
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   f32x4 u[2][2][2];
   const float* ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + lane * 4;
   auto load_u = [&](int chunk, int kk) {             // the four fragments of half a chunk (channels 8 kk .. 8 kk + 7)
+    if ((DBG & 16) && chunk != c_begin) return;
     const float* q = ubase + (size_t)chunk * 16 * 1024;
 #pragma unroll
     for (int pj = 0; pj < 2; ++pj)
@@ -275,6 +282,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
     for (int m = 0; m < 2; ++m)
       a[m] = *reinterpret_cast<const f32x4*>(vw + (pj * WT + m * 32 + (lane & 31)) * WRS + kk * 8 + kh);
+    if (DBG & 1) {               // keep the operands live, issue no MFMA
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[pj][m][n][0] += a[m][0] * u[pj][n][kk][0];
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       t_finish(2 + (rot ^ 1), da, db);
       if (more) load_u(c_begin + i + 1, 0);
       __syncthreads();
-      if (i + 2 < nck) {
+      if (i + 2 < nck && !(DBG & 32)) {
         store_raw(rcur);
         if (i + 3 < nck) load_raw(c_begin + i + 3);
       }
@@ -348,6 +362,19 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   //   wh == 0 (j = 0, 1): P_0 = M0 + M1, P_1 = M1          wh == 1 (j = 2, 3): P_0 = M2, P_1 = -M2 - M3
   // then Y[p][q] = sum_i A^T[p][i] (P_q(i,0) + P_q(i,1)) through LDS in a FIXED order, one 32-tile x 32-channel block
   // per round (4 rounds).
+  if (DBG & 8) {                 // one store per thread keeps the accumulators live
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += acc[a][b][c][r];
+    p.out[(size_t)bid * WNT + tid] = s;
+    return;
+  }
   __syncthreads();
   float* exch = smem;                                              // [8 waves][2 q][32][WLDT]
   double* part = reinterpret_cast<double*>(smem);                  // statistics: [512 threads][2 e][8], after the reads
@@ -478,9 +505,29 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const int nch = wino_chunks(p);
   if (p.ksplit > 1 && (long)(p.ksplit - 1) * ((nch + p.ksplit - 1) / p.ksplit) >= nch) { set_error("conv: ksplit %d leaves an empty split over %d chunks", p.ksplit, nch); return SR3_E_BADARG; }
   dim3 grid((unsigned)wino_workgroups(p, g), p.ksplit);
-  static std::atomic<uint64_t> done{0};
-  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino), W_SMEM, done)) return rc;
-  hipLaunchKernelGGL(k_conv3x3_wino, grid, dim3(WNT), W_SMEM, st, p, g, ufrag);
+  static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
+#define SR3_WINO_LAUNCH(D)                                                                                   \
+  {                                                                                                          \
+    static std::atomic<uint64_t> done{0};                                                                    \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D>), W_SMEM, done)) return rc;  \
+    hipLaunchKernelGGL(k_conv3x3_wino<D>, grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                         \
+  }
+  switch (dbg) {
+    case 0: SR3_WINO_LAUNCH(0) break;
+#ifdef SR3_WINO_ABLATIONS
+    case 1: SR3_WINO_LAUNCH(1) break;
+    case 2: SR3_WINO_LAUNCH(2) break;
+    case 4: SR3_WINO_LAUNCH(4) break;
+    case 8: SR3_WINO_LAUNCH(8) break;
+    case 16: SR3_WINO_LAUNCH(16) break;
+    case 32: SR3_WINO_LAUNCH(32) break;
+    case 38: SR3_WINO_LAUNCH(38) break;       // MFMA + U + epilogue only
+    case 46: SR3_WINO_LAUNCH(46) break;       // MFMA + U only
+    case 62: SR3_WINO_LAUNCH(62) break;       // bare MFMA loop
+#endif
+    default: set_error("conv: SR3_WINO_DBG=%d is not built (compile with -DSR3_WINO_ABLATIONS)", dbg); return SR3_E_BADARG;
+  }
+#undef SR3_WINO_LAUNCH
   SR3_LAUNCH_CHECK("k_conv3x3_wino");
   return SR3_OK;
 }

@@ -12,21 +12,25 @@ class DeviceBatches(object):
     """Iterable over a uint8 DataLoader that yields the reference's batch dicts with device-resident fp32 tensors.
     `len()`, iteration order and the dict keys are the DataLoader's; `.dataset` / `.batch_size` pass through."""
 
-    def __init__(self, loader, device=None, min_max=(-1, 1)):
+    def __init__(self, loader, device=None, min_max=(-1, 1), deal_waves=False):
         self.loader = loader
         self.device = device
         self.min_max = min_max
         self.dataset = loader.dataset
         self.batch_size = loader.batch_size
         self.epoch = 0               # reshuffles a rank-sharded sampler every pass (DistributedSampler.set_epoch)
+        self.deal_waves = deal_waves
 
     def __len__(self):
         return len(self.loader)
 
-    def __iter__(self):
+    def _device_batches(self):
         import data.util as Util
         sampler = getattr(self.loader, 'sampler', None)
         if hasattr(sampler, 'set_epoch'):
+            if self.epoch == 0:
+                from sr3_hip import dist as _dist
+                self.epoch = _dist.resume_epoch      # a resumed run continues the reshuffle sequence
             sampler.set_epoch(self.epoch)
         self.epoch += 1
         for batch in self.loader:
@@ -39,13 +43,37 @@ class DeviceBatches(object):
                     out[k] = v
             yield out
 
+    def __iter__(self):
+        _, world = _dp()
+        from sr3_hip.dist import dp_active
+        if not (self.deal_waves and dp_active()):
+            yield from self._device_batches()
+            return
+        # data-parallel validation: every rank walks ALL items in order, `world` at a time; the wave object lets
+        # DDPM.test run item k's reverse chain on rank k only and share the finished images (sr3_hip.dist.ValWave)
+        from sr3_hip.dist import ValWave
+        group = []
+
+        def flush():
+            wave = ValWave([b['SR'] for b in group])
+            for pos, b in enumerate(group):
+                b['_dp_wave'], b['_dp_pos'] = wave, pos
+                yield b
+        for b in self._device_batches():
+            group.append(b)
+            if len(group) == world:
+                yield from flush()
+                group = []
+        if group:
+            yield from flush()
+
 
 def _dp():
-    """(rank, world) of the data-parallel job this process belongs to; (0, 1) outside torch.distributed."""
-    import torch.distributed as tdist
-    if tdist.is_available() and tdist.is_initialized():
-        return tdist.get_rank(), tdist.get_world_size()
-    return 0, 1
+    """(rank, world) of the data-parallel job this process belongs to; (0, 1) for a single process.  sr.py builds its
+    loaders BEFORE the model (sr.py:52-66), so this is where a torchrun-started script usually joins the job."""
+    from sr3_hip.dist import bootstrap
+    rank, world, _ = bootstrap()
+    return rank, world
 
 
 def create_dataloader(dataset, dataset_opt, phase, device=None):
@@ -59,13 +87,19 @@ def create_dataloader(dataset, dataset_opt, phase, device=None):
             if bs % world:
                 raise ValueError('batch_size %d is not divisible by the %d data-parallel ranks' % (bs, world))
             bs //= world
+            # the permutation seed comes from the global torch RNG like RandomSampler's (so `torch.manual_seed` governs
+            # the order as it does in the reference) -- rank 0's draw, shared, so the shards stay disjoint
+            from sr3_hip.dist import broadcast_int
+            seed = broadcast_int(int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFF)
             sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank,
-                                                                      shuffle=bool(shuffle), drop_last=False)
+                                                                      shuffle=bool(shuffle), seed=seed, drop_last=False)
             shuffle = False
         loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=shuffle, sampler=sampler,
                                              num_workers=dataset_opt['num_workers'], pin_memory=True)
     elif phase == 'val':
+        _dp()
         loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1, pin_memory=True)
+        return DeviceBatches(loader, device, deal_waves=True)
     else:
         raise NotImplementedError('Dataloader [{:s}] is not found.'.format(phase))
     return DeviceBatches(loader, device)

@@ -9,7 +9,8 @@ from torch import nn
 
 
 def _to_device(value, device):
-    return value if value is None else value.to(device)
+    # tensors / modules move; None and plain Python values (the data-parallel loader's bookkeeping entries) pass through
+    return value.to(device) if hasattr(value, 'to') else value
 
 
 class BaseModel(object):
@@ -18,8 +19,17 @@ class BaseModel(object):
 
     def __init__(self, opt):
         self.opt = opt
-        # 'cuda' is HIP on ROCm; with gpu_ids unset the object can be built (checkpoint I/O) but the engine refuses to run
-        self.device = torch.device('cpu' if opt['gpu_ids'] is None else 'cuda')
+        # 'cuda' is HIP on ROCm; with gpu_ids unset the object can be built (checkpoint I/O) but the engine refuses to run.
+        # One process per GPU: inside a data-parallel job the model lives on this rank's own device (cuda:LOCAL_RANK,
+        # already made current by sr3_hip.dist.bootstrap), where the reference's DataParallel root is always cuda:0.
+        from sr3_hip import dist as _dist
+        _, world, local = _dist.bootstrap()
+        if opt['gpu_ids'] is None:
+            self.device = torch.device('cpu')
+        elif world > 1 and torch.cuda.is_available():
+            self.device = torch.device('cuda', local)
+        else:
+            self.device = torch.device('cuda')
         self.begin_step = self.begin_epoch = 0
 
     def set_device(self, x):

@@ -11,6 +11,8 @@ from collections import OrderedDict
 
 import torch
 
+from sr3_hip import dist as _dist
+
 from . import networks
 from .base_model import BaseModel
 
@@ -40,6 +42,11 @@ class DDPM(BaseModel):
             self.optG = make_optimizer(self.netG, lr=opt['train']['optimizer']['lr'])
             self.log_dict = OrderedDict()
         self.load_network()
+        # data parallel: equalise the replicas once (each process initialised its own weights; a resumed checkpoint is
+        # already identical) -- the counterpart of DataParallel's per-step replicate (model/networks.py:113-115)
+        self._sam_wave = None
+        if _dist.dp_active():
+            _dist.sync_replicas(self.netG.denoise_fn)
         self.print_network()
 
     # ---- data / step ---------------------------------------------------------------------------
@@ -53,21 +60,31 @@ class DDPM(BaseModel):
         b, c, h, w = self.data['HR'].shape
         # data parallel: the engine returns the loss summed over ALL ranks, so normalise by the global element count
         # (the reference's `l_pix.sum() / int(b*c*h*w)` over DataParallel's gathered per-replica sums, :52-53)
-        from sr3_hip.dist import dp_world_size
-        l_pix = l_pix.sum() / int(b * c * h * w * dp_world_size(self.netG.denoise_fn))
+        l_pix = l_pix.sum() / int(b * c * h * w * _dist.dp_world_size())
         self.optG.step()
         self.log_dict['l_pix'] = l_pix.item()
 
     def test(self, continous=False):
         self.netG.eval()
         with torch.no_grad():
-            self.SR = self.netG.super_resolution(self.data['SR'], continous)
+            wave = self.data.get('_dp_wave') if isinstance(self.data, dict) else None
+            if wave is not None and _dist.dp_active():
+                # data parallel: the loader deals consecutive validation items over the ranks (sr3_hip.dist.ValWave);
+                # this item's chain ran on one rank, every rank gets the same image back
+                self.SR = wave.result(self.netG, self.data['_dp_pos'], continous)
+            else:
+                self.SR = self.netG.super_resolution(self.data['SR'], continous)
         self.netG.train()
 
     def sample(self, batch_size=1, continous=False):
         self.netG.eval()
         with torch.no_grad():
-            self.SR = self.netG.sample(batch_size, continous)
+            if _dist.dp_active():
+                if self._sam_wave is None:
+                    self._sam_wave = _dist.SampleWave()
+                self.SR = self._sam_wave.next(self.netG, batch_size, continous)
+            else:
+                self.SR = self.netG.sample(batch_size, continous)
         self.netG.train()
 
     def set_loss(self):
@@ -97,6 +114,8 @@ class DDPM(BaseModel):
         return out
 
     def print_network(self):
+        if not _dist.is_primary():
+            return
         s, n = self.get_network_description(self.netG)
         logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
         logger.info(s)
@@ -108,11 +127,13 @@ class DDPM(BaseModel):
     def save_network(self, epoch, iter_step):
         stem = os.path.join(self.opt['path']['checkpoint'], 'I{}_E{}'.format(iter_step, epoch))
         gen_path, opt_path = self._ckpt_paths(stem)
-        state = OrderedDict((k, v.cpu()) for k, v in self.netG.state_dict().items())
-        torch.save(state, gen_path)
-        torch.save({'epoch': epoch, 'iter': iter_step, 'scheduler': None,
-                    'optimizer': self.optG.state_dict()}, opt_path)
-        logger.info('Saved model in [{:s}] ...'.format(gen_path))
+        if _dist.is_primary():          # replicas are identical: one writer
+            state = OrderedDict((k, v.cpu()) for k, v in self.netG.state_dict().items())
+            torch.save(state, gen_path)
+            torch.save({'epoch': epoch, 'iter': iter_step, 'scheduler': None,
+                        'optimizer': self.optG.state_dict()}, opt_path)
+            logger.info('Saved model in [{:s}] ...'.format(gen_path))
+        _dist.barrier()                 # nobody runs ahead (or resumes) before the files are complete
 
     def load_network(self):
         stem = self.opt['path']['resume_state']
@@ -127,3 +148,4 @@ class DDPM(BaseModel):
             self.optG.load_state_dict(ck['optimizer'])
             self.begin_step = ck['iter']
             self.begin_epoch = ck['epoch']
+            _dist.resume_epoch = int(ck['epoch'])

@@ -307,9 +307,7 @@ class EngineDiffusion(nn.Module):
         x_start = x_in['HR'].contiguous()
         b, c, h, w = x_start.shape
         dev = x_start.device
-        if dev.type != 'cuda':
-            raise L.Sr3Error('training needs the model on a GPU; there is no CPU fallback')
-        un = self.denoise_fn
+        un = self.denoise_fn           # (a CPU tensor is refused by the engine call: there is no CPU fallback)
         level = tstep = None
         if self.variant == 'sr3':
             if gamma is None:

@@ -1,23 +1,147 @@
 """Multi-GPU plumbing: one process per GPU (torch.distributed; backend 'nccl' is RCCL on ROCm).
 
-The reference's only multi-GPU mechanism is single-process nn.DataParallel (model/networks.py:113-115).
-Here sampling shards the image list across ranks -- every reverse chain is independent
-(GroupNorm is per sample, attention per image), so there is NO collective in the data path; the
-only collectives are an optional all_gather of the finished images and the barrier / MAX-reduce
-around a timed region.  Each rank keeps a full weight replica (391 MB for SR3 16->128).
+The reference's only multi-GPU mechanism is single-process nn.DataParallel (model/networks.py:113-115, switched on
+by core/logger.py:49-59 when more than one gpu id is listed).  Here the same callers (sr.py / infer.py / sample.py,
+unchanged) are started once per GPU by `python -m torch.distributed.run`, and the drop-in packages join the job by
+themselves: `bootstrap()` is called by `model.create_model` and `data.create_dataloader` (whichever the script reaches
+first), picks `cuda:LOCAL_RANK`, creates the RCCL process group and gives every rank its own RNG stream.
+
+* Training: the loader shards the GLOBAL batch over the ranks, `sr3_train_step` marks gradient buckets ready as the
+  backward produces them and `GradReducer` all-reduces them on a side stream; every rank applies the same Adam step.
+* Sampling / validation: every reverse chain is independent (GroupNorm is per sample, attention per image), so there
+  is NO collective in the reverse loop; `ValWave` / `SampleWave` deal consecutive validation items (or `sample()`
+  calls) round-robin over the ranks and all-gather only the finished images, so every rank's caller sees the same
+  sequence of results a single process would produce, N images at a time.
 """
+import os
 import time
 
 import torch
 
+_BOOT = None          # (rank, world, local_rank) once bootstrap() has run
+force_collectives = False     # SR3_DP=force: keep the gradient all-reduce on even with one rank (tests on a 1-GPU box)
+resume_epoch = 0      # set by DDPM.load_network: the training loader (built before the model, sr.py:52-66) continues
+                      # its per-epoch reshuffle sequence from here instead of replaying epoch 0's order after a resume
 
-def dp_world_size(unet=None):
-    """Ranks that share one training step (1 outside torch.distributed); `unet.force_dp` keeps the collective path
-    on with a single rank (tests)."""
+
+def _env_int(name, default):
+    v = os.environ.get(name)
+    return default if v in (None, '') else int(v)
+
+
+def bootstrap():
+    """Join the data-parallel job the launcher's environment describes; idempotent; returns (rank, world, local_rank).
+
+    No WORLD_SIZE > 1 in the environment and no process group => (0, 1, 0) and nothing is touched.  Otherwise (torchrun /
+    torch.distributed.run env: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT): the current device becomes
+    `cuda:LOCAL_RANK` and a process group is created -- 'nccl' (= RCCL) bound to that device when a GPU is visible, 'gloo'
+    otherwise (CPU tests) -- unless the caller already made one.  The torch RNG of rank r is re-seeded to
+    `initial_seed + r * 1000003` so ranks draw different z / dropout seeds (numpy's global RNG, which draws the SR3
+    training timestep, is entropy-seeded per process).  `SR3_DP=0` opts out: the processes stay independent replicas;
+    `SR3_DP=force` creates the group even for WORLD_SIZE=1 and keeps the collectives on (tests)."""
+    global _BOOT
+    import torch.distributed as tdist
+    if _BOOT is not None and (_BOOT[1] == 1 or tdist.is_initialized()):
+        return _BOOT
+    if not tdist.is_available():
+        _BOOT = (0, 1, 0)
+        return _BOOT
+    local = _env_int('LOCAL_RANK', 0)
+    if tdist.is_initialized():
+        _BOOT = (tdist.get_rank(), tdist.get_world_size(), local)
+        return _BOOT
+    world = _env_int('WORLD_SIZE', 1)
+    mode = os.environ.get('SR3_DP', '1')
+    force = mode == 'force' and 'WORLD_SIZE' in os.environ      # tests: a 1-rank job that still takes the collective path
+    if (world <= 1 and not force) or mode == '0':
+        _BOOT = (0, 1, 0)
+        return _BOOT
+    global force_collectives
+    force_collectives = force
+    rank = _env_int('RANK', 0)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+    if 'MASTER_PORT' not in os.environ:
+        raise RuntimeError('WORLD_SIZE=%d but MASTER_PORT is not set: start the script with '
+                           '`python -m torch.distributed.run --nproc-per-node N ...`' % world)
+    if torch.cuda.is_available():
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev:
+            raise RuntimeError('rank %d wants cuda:%d but only %d device(s) are visible: list one gpu id per rank '
+                               '(e.g. `-gpu %s`; core/logger.py exports it as CUDA_VISIBLE_DEVICES)'
+                               % (rank, local, n_dev, ','.join(str(i) for i in range(world))))
+        torch.cuda.set_device(local)
+        tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
+    else:
+        tdist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(torch.initial_seed() + rank * 1000003)
+    _BOOT = (rank, world, local)
+    return _BOOT
+
+
+def dp_info():
+    """(rank, world, local_rank) without creating anything: the bootstrap result, else the live process group."""
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
-        return tdist.get_world_size()
-    return 1
+        return tdist.get_rank(), tdist.get_world_size(), _env_int('LOCAL_RANK', 0)
+    return 0, 1, 0
+
+
+def dp_active():
+    """True when the collective paths are on: more than one rank, or a forced 1-rank job (SR3_DP=force)."""
+    import torch.distributed as tdist
+    rank, world, _ = dp_info()
+    return world > 1 or (force_collectives and tdist.is_available() and tdist.is_initialized())
+
+
+def is_primary():
+    """True on the rank that writes checkpoints / images / the network description (rank 0, or any single process)."""
+    return dp_info()[0] == 0
+
+
+def _coll_device():
+    """Where a small collective's tensor has to live: the current GPU under RCCL, the host under gloo."""
+    import torch.distributed as tdist
+    if tdist.get_backend() == 'nccl':
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def broadcast_int(value, src=0):
+    """One int64 from rank `src` to every rank (sampler seeds, begin_epoch)."""
+    import torch.distributed as tdist
+    if dp_info()[1] == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_coll_device())
+    tdist.broadcast(t, src)
+    return int(t.item())
+
+
+def sync_replicas(unet, src=0):
+    """Make every rank's parameters rank `src`'s: one broadcast of the packed arena (+ the DDPM frequency table).  The
+    reference has one copy of the weights that DataParallel re-broadcasts every step (model/networks.py:113-115); here
+    replicas persist, so they are equalised once -- after init / checkpoint load -- and stay equal because every rank
+    applies the same Adam update to the same all-reduced gradient."""
+    import torch.distributed as tdist
+    if not dp_active():
+        return
+    arena = unet.arena.data
+    if tdist.get_backend() == 'nccl' and not arena.is_cuda:
+        raise RuntimeError('sync_replicas: move the model to its GPU first')
+    tdist.broadcast(arena, src)
+    tdist.broadcast(unet.freq, src)
+    unet.weights_changed()
+
+
+def barrier():
+    import torch.distributed as tdist
+    if dp_info()[1] > 1:
+        tdist.barrier()
+
+
+def dp_world_size():
+    """Ranks that share one training step (1 outside torch.distributed)."""
+    return dp_info()[1]
 
 
 def shard_range(n_items, rank, world):
@@ -107,6 +231,8 @@ class GradReducer(object):
     def mark_args(self):
         """(n, offsets array, event-handle array) for sr3_train_step."""
         import ctypes as C
+        if not self.cuda:
+            return 0, None, None
         n = len(self.buckets)
         offs = (C.c_size_t * n)(*[lo for lo, _ in self.buckets])
         evs = (C.c_void_p * n)(*[ev.cuda_event for ev in self.events])
@@ -133,3 +259,74 @@ class GradReducer(object):
             if extra is not None:
                 for t in extra:
                     d.all_reduce(t, op=d.ReduceOp.SUM)
+
+
+# ---- validation / unconditional sampling: consecutive items dealt round-robin over the ranks ----------------
+def _gather_padded(own, template_shape, world, tdist, dev):
+    """all_gather of one same-shaped tensor per rank (`own` None => zeros of template_shape)."""
+    if own is None:
+        own = torch.zeros(template_shape, dtype=torch.float32, device=dev)
+    parts = [torch.empty_like(own) for _ in range(world)]
+    tdist.all_gather(parts, own.contiguous())
+    return parts
+
+
+class ValWave(object):
+    """Up to `world` consecutive validation batches.  Every rank iterates ALL of them in order (so the caller's idx,
+    file names and PSNR average are those of a single process -- sr.py:112-141, infer.py:64-90), but the reverse chain
+    of item k runs only on rank k, once, when the first item of the wave is tested; the finished images are all-gathered
+    and `DDPM.test` hands item k's to the caller when it gets there.  Rides in the batch dict under '_dp_wave'."""
+
+    def __init__(self, conds):
+        self.conds = conds            # list of (B, 3, H, W) conditioning tensors ('SR' entries), one per item
+        self.results = None
+        self.continous = None
+
+    def to(self, *args, **kwargs):    # feed_data moves every dict entry with .to(device)
+        return self
+
+    def run(self, netG, continous):
+        import torch.distributed as tdist
+        rank, world, _ = dp_info()
+        n = len(self.conds)
+        own = None
+        if rank < n:
+            own = netG.super_resolution(self.conds[rank], continous)
+        # every item of a validation loader has the same shape (batch 1, fixed resolution) and rank 0 always has one:
+        # its result shape tells the item-less ranks of a ragged last wave what to contribute
+        meta = torch.zeros(6, dtype=torch.int64, device=_coll_device())
+        if own is not None:
+            meta[0] = own.dim()
+            meta[1:1 + own.dim()] = torch.tensor(list(own.shape), dtype=torch.int64)
+        tdist.broadcast(meta, 0)
+        dims = [int(v) for v in meta[1:1 + int(meta[0])].tolist()]
+        dev = own.device if own is not None else self.conds[0].device
+        parts = _gather_padded(own, dims, world, tdist, dev)
+        self.results = parts[:n]
+        self.continous = continous
+
+    def result(self, netG, pos, continous):
+        if self.results is None or self.continous != continous:
+            self.run(netG, continous)
+        return self.results[pos]
+
+
+class SampleWave(object):
+    """The same dealing for `DDPM.sample()` (sample.py:104,140 call it `data_len` times): call k of a wave of `world`
+    calls returns rank k's draw; the wave is sampled when its first call arrives."""
+
+    def __init__(self):
+        self.results = []
+        self.key = None
+
+    def next(self, netG, batch_size, continous):
+        import torch.distributed as tdist
+        rank, world, _ = dp_info()
+        key = (int(batch_size), bool(continous))
+        if not self.results or self.key != key:
+            own = netG.sample(batch_size, continous)
+            parts = [torch.empty_like(own) for _ in range(world)]
+            tdist.all_gather(parts, own.contiguous())
+            self.results = parts
+            self.key = key
+        return self.results.pop(0)

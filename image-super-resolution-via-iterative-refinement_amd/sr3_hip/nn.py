@@ -103,7 +103,7 @@ class EngineUNet(nn.Module):
         arena = self.arena
         if not arena.is_cuda:
             return
-        key = (arena.data_ptr(), arena._version, self._weights_epoch)
+        key = (arena.data_ptr(), arena._version, self._weights_epoch, self.plan.generation)
         if key == self._derived_key:
             return
         import ctypes as C
@@ -187,12 +187,42 @@ class EngineUNet(nn.Module):
 
     # ---- training step (forward + backward inside the engine) ------------------------------------
     def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, drop_seed=None):
-        import ctypes as C
-        self.ensure_derived()          # the train plan's block1 / Upsample convs run on the Winograd kernel
+        """One fused forward + backward: returns the sum-reduced loss (0-dim tensor, summed over all data-parallel
+        ranks) and leaves d(loss * grad_scale)/d params -- rank-summed -- in `grad_arena`."""
         p_drop = self.dropout if self.training else 0.0
         if drop_seed is None:          # a fresh mask every step, drawn from torch's CPU generator
             drop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0 else 0
         dev = hr.device
+        if getattr(self, 'grad_arena', None) is None or self.grad_arena.device != dev:
+            self.grad_arena = torch.zeros_like(self.arena.data)
+        loss = torch.zeros(1, device=dev)
+        # data parallel (one process per GPU): gradients are summed over ranks, so the 1/(b c h w) factor
+        # uses the GLOBAL batch (model/model.py:52-53 under DataParallel); buckets reduce as they get ready
+        import torch.distributed as tdist
+        from . import dist as _dist
+        dp = _dist.dp_world_size() > 1 or ((getattr(self, 'force_dp', False) or _dist.force_collectives)
+                                          and tdist.is_available() and tdist.is_initialized())
+        red, marks = None, (0, None, None)
+        if dp:
+            from .dist import GradReducer
+            red = getattr(self, '_reducer', None)
+            if red is None or red.device != dev:
+                red = self._reducer = GradReducer(self.arena.numel(), dev, tdist)
+            grad_scale = grad_scale / tdist.get_world_size()
+            marks = red.mark_args()
+        self._engine_train_step(hr, cond, z, ca, cb, level, tstep, grad_scale, p_drop, drop_seed, marks, loss)
+        if dp:
+            red.reduce(self.grad_arena, extra=[loss])
+        return loss[0]
+
+    def _engine_train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, p_drop, drop_seed, marks, loss):
+        """The sr3_train_step call itself (q_sample -> UNet forward -> loss -> backward, `marks` = the gradient-ready
+        events of the data-parallel buckets)."""
+        import ctypes as C
+        dev = hr.device
+        if dev.type != 'cuda':
+            raise L.Sr3Error('training needs the model on a GPU; there is no CPU fallback')
+        self.ensure_derived()          # the train plan's block1 / Upsample convs run on the Winograd kernel
         B = hr.shape[0]
         plan = self.plan
         cc = 0 if cond is None else cond.shape[1]
@@ -204,30 +234,12 @@ class EngineUNet(nn.Module):
             ws = self._train_ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
         off = (-ws.data_ptr()) % 256
         wsv = ws[off:off + need]
-        if getattr(self, 'grad_arena', None) is None or self.grad_arena.device != dev:
-            self.grad_arena = torch.zeros_like(self.arena.data)
-        loss = torch.zeros(1, device=dev)
+        n_marks, offs, evs = marks
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        # data parallel (one process per GPU): gradients are summed over ranks, so the 1/(b c h w) factor
-        # uses the GLOBAL batch (model/model.py:52-53 under DataParallel); buckets reduce as they get ready
-        import torch.distributed as tdist
-        from .dist import dp_world_size
-        dp = dp_world_size() > 1 or (getattr(self, 'force_dp', False) and tdist.is_available() and tdist.is_initialized())
-        n_marks, offs, evs = 0, None, None
-        if dp:
-            from .dist import GradReducer
-            red = getattr(self, '_reducer', None)
-            if red is None or red.device != dev:
-                red = self._reducer = GradReducer(self.arena.numel(), dev, tdist)
-            grad_scale = grad_scale / tdist.get_world_size()
-            n_marks, offs, evs = red.mark_args()
         L.check(plan.lib.sr3_train_step(plan.handle, L.ptr(hr), L.ptr(cond), cc, L.ptr(z), L.ptr(ca), L.ptr(cb),
                                         L.ptr(level), L.ptr(tstep), L.ptr(self.freq), L.ptr(self.arena.data),
                                         L.ptr(self.grad_arena), L.ptr(wsv), need, L.ptr(loss), C.c_float(grad_scale),
                                         C.c_float(p_drop), C.c_uint(drop_seed & 0xFFFFFFFF), n_marks, offs, evs, B, stream))
-        if dp:
-            red.reduce(self.grad_arena, extra=[loss])
-        return loss[0]
 
     def named_gradients(self):
         """(reference key, gradient view in the reference shape) after a train_step."""

@@ -1,0 +1,132 @@
+"""One rank of the drop-in data-parallel test (tests/test_dist_dropin.py starts it N times through
+`python -m torch.distributed.run`, exactly as a user would start sr.py).  It replays sr.py's call sequence
+(reference sr.py:52-100 training, :104-141 in-training validation, :164-166 checkpoint) against the drop-in `data`,
+`model` and `core.metrics` packages WITHOUT initialising torch.distributed itself: joining the job is the packages'
+business.  There is no GPU here, so the two engine calls (`EngineUNet._engine_train_step`, the reverse loop behind
+`super_resolution`) and the fused Adam kernel are replaced by deterministic CPU stand-ins; everything around them --
+bootstrap, loader sharding, replica sync, gradient bucket all-reduce, loss normalisation, validation waves, rank-0
+checkpointing -- is the shipped code.  Writes what it saw to <out>/rank<r>.pt."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
+for p in (os.path.join(ROOT, 'tests'), ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from helpers import opt_for                                     # noqa: E402
+
+
+class _Pairs(torch.utils.data.Dataset):
+    """uint8 HWC items in the drop-in dataset's format (data/LRHR_dataset.py)."""
+
+    def __init__(self, n, size=16):
+        self.n, self.size = n, size
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(1000 + i)
+        hr = torch.randint(0, 256, (self.size, self.size, 3), generator=g, dtype=torch.uint8)
+        sr = torch.randint(0, 256, (self.size, self.size, 3), generator=g, dtype=torch.uint8)
+        return {'HR': hr, 'SR': sr, 'Index': i, 'flip': False}
+
+
+def _cpu_u8_to_f32(v, flip, min_max, device, out=None):         # stands in for the sr3_images_u8_to_f32 kernel
+    return v.permute(0, 3, 1, 2).float() / 255.0 * (min_max[1] - min_max[0]) + min_max[0]
+
+
+def main():
+    out_dir = sys.argv[1]
+    import torch.distributed as tdist
+    assert not tdist.is_initialized()
+    import data as Data
+    import data.util as Util
+    import model as Model
+    import core.metrics as Metrics
+    from sr3_hip import dist as D
+    from sr3_hip.nn import EngineUNet
+    from sr3_hip.optim import EngineAdam
+    Util.u8_batch_to_f32 = _cpu_u8_to_f32
+
+    def fake_engine_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, p_drop, drop_seed, marks, loss):
+        # "gradient" = a fixed direction scaled by this rank's data, carrying the 1/(GLOBAL b c h w) factor it was handed
+        n = self.arena.numel()
+        self.grad_arena.copy_(torch.linspace(1.0, 2.0, n) * float(hr.double().sum()) * grad_scale)
+        loss[0] = float((hr - cond).abs().double().sum())
+
+    def fake_adam(self):
+        un = self.netG.denoise_fn
+        un.arena.data.sub_(self.defaults['lr'] * un.grad_arena)
+        un.weights_changed()
+
+    EngineUNet._engine_train_step = fake_engine_step
+    EngineAdam.step = fake_adam
+
+    opt = opt_for('sr3_tiny', phase='train', gpu=False)
+    opt['gpu_ids'] = None
+    opt['path'] = {'checkpoint': out_dir, 'resume_state': None}
+    rec = {}
+    # sr.py:52-60 -- loaders first
+    train_set, val_set = _Pairs(16), _Pairs(5)
+    train_loader = Data.create_dataloader(train_set, dict(batch_size=4, use_shuffle=True, num_workers=0), 'train')
+    val_loader = Data.create_dataloader(val_set, dict(), 'val')
+    launched = int(os.environ.get('WORLD_SIZE', '1')) > 1
+    assert tdist.is_initialized() == launched, 'create_dataloader did not join the job'
+    rank, world, _ = D.dp_info()
+    rec['rank'], rec['world'] = rank, world
+    rec['torch_seed'] = torch.initial_seed()
+    # sr.py:66 -- the model: every rank initialises its own (different) weights, create_model equalises them
+    torch.manual_seed(1234 + 77 * rank)
+    diffusion = Model.create_model(opt)
+    un = diffusion.netG.denoise_fn
+    rec['w_init'] = un.arena.data.clone()
+    rec['device'] = str(diffusion.device)
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
+    # sr.py:81-100 -- two epochs of steps
+    seen, lpix = [], []
+    step = 0
+    for epoch in range(2):
+        for train_data in train_loader:
+            step += 1
+            seen.append(train_data['Index'].tolist())
+            diffusion.feed_data(train_data)
+            diffusion.optimize_parameters()
+            lpix.append(diffusion.get_current_log()['l_pix'])
+    rec['seen'], rec['l_pix'], rec['w_final'] = seen, lpix, un.arena.data.clone()
+    # the value a single process would log for the same global batch (model/model.py:52-53)
+    # sr.py:104-141 -- validation inside training
+    calls = []
+
+    def fake_super_resolution(x_in, continous=False):
+        calls.append(float(x_in.sum()))
+        img = x_in * 0.5 + rank            # tagged with the rank that produced it
+        return torch.cat([x_in, img], 0) if continous else img[-1]
+    diffusion.netG.super_resolution = fake_super_resolution
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+    val = []
+    for idx, val_data in enumerate(val_loader):
+        diffusion.feed_data(val_data)
+        diffusion.test(continous=False)
+        vis = diffusion.get_current_visuals()
+        val.append((int(val_data['Index'][0]), vis['SR'].clone(), vis['HR'].clone()))
+        Metrics.save_img((np.clip(vis['SR'].permute(1, 2, 0).numpy(), 0, 1) * 255).astype(np.uint8),
+                         os.path.join(out_dir, 'val_%d_sr_rank%d.png' % (idx, rank)))
+    rec['val'], rec['sr_calls'] = val, calls
+    diffusion.set_new_noise_schedule(opt['model']['beta_schedule']['train'], schedule_phase='train')
+    # sr.py:164-166
+    diffusion.save_network(1, step)
+    rec['ckpt_exists_after_save'] = os.path.exists(os.path.join(out_dir, 'I%d_E1_gen.pth' % step))
+    torch.save(rec, os.path.join(out_dir, 'rank%d.pt' % rank))
+    if launched:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,4 +1,6 @@
-"""Data-parallel training step over RCCL, one process per GPU, against the CPU oracle on the CONCATENATED batch:
+"""Data-parallel training step over RCCL, one process per GPU, REACHED THROUGH THE DROP-IN (the ranks only get the launcher's
+environment variables; `model.create_model` joins the job, picks cuda:LOCAL_RANK and equalises the replicas), against the
+CPU oracle on the CONCATENATED batch:
 rank-summed gradients (all-reduced in tail-first buckets on a side stream) == d(sum-reduced loss / GLOBAL b*c*h*w) and
 the logged l_pix == the reference's value over the global batch (model/model.py:52-53 under nn.DataParallel,
 model/networks.py:113-115).  world = 1 runs on any GPU box (collective path forced on); world = 2 needs two GPUs and is
@@ -34,25 +36,27 @@ def _rank_main(rank, world, port, ret):
     for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # what `python -m torch.distributed.run` exports for each rank -- and nothing else: no init_process_group here
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), SR3_DP='force')          # 'force': world 1 keeps the collective path on
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
-    dev = torch.device('cuda', rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    assert not dist.is_initialized()
     try:
         import model as Model
         from sr3_hip.dist import GradReducer
         opt = opt_for(NAME, phase='train', gpu=True)
+        torch.manual_seed(7 + rank)                         # every rank initialises different weights ...
         m = Model.create_model(opt)
-        m.device = dev
-        m.netG = m.netG.to(dev)
-        m.netG.set_new_noise_schedule(opt['model']['beta_schedule']['train'], dev)
+        assert dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == world
+        dev = torch.device('cuda', rank)
+        assert m.device == dev and torch.cuda.current_device() == rank
+        assert m.netG.denoise_fn.arena.device == dev
+        w0 = [torch.empty_like(m.netG.denoise_fn.arena.data) for _ in range(world)]
+        dist.all_gather(w0, m.netG.denoise_fn.arena.data)
+        assert all(torch.equal(w0[0], w) for w in w0)       # ... create_model broadcast rank 0's
         _, sd = load_golden(NAME)
         m.netG.load_state_dict(sd, strict=True)
         un = m.netG.denoise_fn
-        un.force_dp = True                                  # world 1: keep the collective path on
         un._reducer = GradReducer(un.arena.numel(), dev, dist, bucket_bytes=16 << 10)    # several buckets
         hr, sr, z, gamma = _inputs(world)
         sl = slice(rank * PER_RANK, (rank + 1) * PER_RANK)
@@ -66,7 +70,8 @@ def _rank_main(rank, world, port, ret):
         ret[rank] = dict(l_pix=m.get_current_log()['l_pix'], grads=grads, buckets=len(un._reducer.buckets),
                          moved=float((un.arena.data - before).abs().max()), weights=un.arena.data.cpu().clone())
     finally:
-        dist.destroy_process_group()
+        if dist.is_initialized():
+            dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)          # a wedged collective must fail this test, not hang the suite
@@ -101,3 +106,70 @@ def test_dp_training_step_matches_oracle_on_the_global_batch(world):
         assert out['moved'] > 0                             # Adam ran after the reduction
     if world > 1:                                           # identical replicas after the step
         assert torch.equal(ret[0]['weights'], ret[1]['weights'])
+
+
+def _val_main(rank, world, port, root, ret):
+    for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    if world:                        # world 0: a plain single process, no launcher environment
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE=str(world), SR3_DP='force')
+    import torch.distributed as dist
+    try:
+        import data as Data
+        import model as Model
+        from sr3_hip import dist as D
+        dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
+        val_loader = Data.create_dataloader(Data.create_dataset(dopt, 'val'), dopt, 'val')     # joins the job (sr.py order)
+        assert dist.is_initialized() == bool(world)
+        opt = opt_for(NAME, phase='val', gpu=True)
+        m = Model.create_model(opt)
+        _, sd = load_golden(NAME)
+        m.netG.load_state_dict(sd, strict=True)
+        m.netG.show_progress = False
+        m.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+        outs, waves = [], []
+        for idx, val_data in enumerate(val_loader):
+            m.feed_data(val_data)
+            waves.append(('_dp_wave' in val_data, val_data.get('_dp_pos')))
+            if val_data.get('_dp_pos', 0) == 0:
+                torch.manual_seed(500 + idx + 31 * rank)        # the wave's chains start here, one per rank
+            m.test(continous=True)
+            outs.append(m.get_current_visuals(need_LR=False)['SR'].clone())
+        ret[rank] = dict(outs=outs, waves=waves, active=D.dp_active())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world', [1, 2])
+def test_validation_waves_through_the_dropin(world, tmp_path):
+    """infer.py / sr.py's validation loop under the launcher environment: every rank sees all items in order, item k's
+    reverse chain runs on rank k % world, the images every rank ends up with are the ones a single process computes for
+    the same per-chain seeds (no collective inside the chain: the results are bit-identical)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip('needs %d GPUs (have %d)' % (world, torch.cuda.device_count()))
+    from test_oracle_io import _write_triplets
+    root = str(tmp_path / 'ds')
+    n_items = 3
+    _write_triplets(root, n_items, l=4, r=16)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_val_main, args=(world, port, root, ret), nprocs=world, join=True)
+    ref = mp.Manager().dict()
+    # single-process references: chain of item k seeded as the wave seeds it on its producing rank
+    for r in range(world):
+        assert ret[r]['active'] and [w[0] for w in ret[r]['waves']] == [True] * n_items
+        assert [w[1] for w in ret[r]['waves']] == [k % world for k in range(n_items)]
+        for k in range(n_items):
+            assert torch.equal(ret[r]['outs'][k], ret[0]['outs'][k])
+    if world == 1:
+        mp.spawn(_val_main, args=(0, port, root, ref), nprocs=1, join=True)
+        assert not ref[0]['active'] and [w[0] for w in ref[0]['waves']] == [False] * n_items
+        for k in range(n_items):
+            assert torch.equal(ref[0]['outs'][k], ret[0]['outs'][k])
