@@ -34,25 +34,35 @@
 // buffer, 16/9 of the 3x3 weights' size); it is never part of a state dict.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "sr3_common.h"
 
 namespace sr3 {
 
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
 namespace {
-constexpr int WT = 64;          // Winograd tiles per workgroup (16 x 16 output pixels)
 constexpr int WBN = 64;         // output channels per workgroup
 constexpr int WCK = 16;         // input channels per chunk
-constexpr int WRS = 20;         // LDS row stride (floats) of the raw halo and of the V planes: 16 + 4 pad
+constexpr int WRS = 20;         // LDS pixel stride (floats) of the raw halo: 16 channels + 4 pad
+constexpr int WROW = 18 * WRS + 8;   // LDS row stride of the raw halo (18 pixels + 8 pad); every second ROW PAIR is shifted by
+constexpr int WSHIFT = 4;            // 4 floats more: with this layout the transform's ds_read_b128 (lane = tile of a 4 x 8
+                                     // tile block, two channel quads) hit 16 distinct bank quads per 16-lane group
 constexpr int WNT = 512;        // threads (8 waves)
 constexpr int WHP = 324;        // raw halo pixels of one tile: 18 x 18
 constexpr int WHI = (WHP * 4 + WNT - 1) / WNT;       // raw float4 items per thread (4 channel quads per pixel)
-constexpr int WLDT = 36;        // epilogue exchange row stride (32 + 4)
-constexpr int W_RAW_F = WHP * WRS;                    // floats per raw buffer (two of them)
-constexpr int W_V_F = 8 * 2 * WT * WRS;               // 8 waves x 2 positions x 64 tiles x stride
-constexpr int W_EXCH_F = 8 * 2 * 32 * WLDT;           // epilogue: 8 waves x 2 (q) x 32 tiles x stride
-constexpr int W_SMEM_MAIN = (2 * W_RAW_F + W_V_F) * 4;
-constexpr int W_SMEM_EPI = W_EXCH_F * 4;               // the exchange block doubles as the statistics parking area
-constexpr int W_SMEM = W_SMEM_MAIN > W_SMEM_EPI ? W_SMEM_MAIN : W_SMEM_EPI;
+constexpr int WETS = 68;        // epilogue exchange: floats per channel row of a plane (64 tiles + 4 pad)
+constexpr int WEPL = 2240;      // ... floats per plane: 32 rows x 68 + the 4-float shift of channels >= 16, padded to 16 bank quads x 35
+constexpr int W_RAW_F = 18 * WROW + 8;                // floats per raw buffer (two of them)
+constexpr int W_EXCH_F = 8 * 2 * WEPL;                // epilogue: 8 waves x 2 (q) planes
+constexpr int W_MAX_CK = 64;                          // chunks of one workgroup's K range (1024 input channels; more: split-K)
+constexpr int W_CST_F = 64 + W_MAX_CK * 2 * WCK;      // per-tile constants: bias + FiLM of 64 output channels, (scale, shift) pairs
+                                                      // BEHIND the exchange block, two of them: the next tile's are written
+                                                      // during the epilogue
+static_assert(2 * W_RAW_F <= W_EXCH_F, "the raw tiles live inside the exchange block's footprint");
+constexpr int W_SMEM = (W_EXCH_F + 2 * W_CST_F) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
+static_assert(W_SMEM <= 163840, "LDS");
 
 // x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e): ~1e-7 absolute error on silu, three instructions
 // instead of libm expf's twelve -- every staged element pays for this once per output-channel block
@@ -129,62 +139,95 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// DBG (profiling ablations only, env SR3_WINO_DBG; 0 in production): 1 skip the MFMAs, 2 skip the GroupNorm / SiLU arithmetic of
-// the staging step, 4 skip the input transforms, 8 skip the epilogue, 16 skip the U loads of the loop, 32 skip the raw staging
-// of the loop (global loads + activation + LDS stores)
+// DBG (profiling only, env SR3_WINO_DBG, library built with -DSR3_WINO_ABLATIONS; 0 in production): 1 skip the MFMAs, 2 skip the
+// GroupNorm / SiLU arithmetic of the staging step, 4 skip the input transforms, 8 skip the epilogue, 16 skip the U loads of the
+// loop, 32 skip the raw staging of the loop, 64 write shader-clock stamps of every tile's phases (tools/wino_phases.py)
+//
+// Memory operations and the in-order vmcnt counter.  Measured on the round-3 phase timeline (profiles/r03d_*): every
+// `s_waitcnt vmcnt(0)` in a tile's prologue / epilogue costs 2-3 k cycles (all CUs hit their tile boundaries together), and
+// the compiler falls back to vmcnt(0) whenever a load sits under a condition or in a loop of unknown length.  So outside the
+// main loop every global load here is UNCONDITIONAL (absent operands are read from a valid dummy address and discarded by a
+// select), issued in one fixed order, and consumed in that order:
+//   epilogue:  [next tile's GroupNorm pairs + bias + FiLM]  [this tile's residual, both rounds]   ... round 0 ...
+//              [next tile's raw chunks 0 and 1]             ... round 1 ...
+//   prologue:  [U fragments of chunk 0]  stage chunks 0, 1  [raw chunk 2]
 template <int DBG>
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
-  float* raw0 = smem;                             // [WHP][WRS] x 2 (double buffered)
+  float* raw0 = smem;                             // [18 rows][WROW] x 2 (double buffered), inside the exchange block's footprint
   float* raw1 = smem + W_RAW_F;
-  float* vbase = smem + 2 * W_RAW_F;              // [8 waves][2][64][WRS]
+  float* cst = smem + W_EXCH_F;                   // per-tile constants, double buffered by tile parity: [W_CST_F] x 2
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform on purpose (an SGPR): everything derived from it -- the transform row, the column pair, the signs -- is then
+  // a scalar branch or a scalar select instead of per-lane v_cndmask work beside the MFMAs
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Cin = p.C0 + p.C1;
   const int H = p.Ho, W = p.Wo;
-  int bid = blockIdx.x;
+  // Persistent workgroups: workgroup b walks the tile list b, b + gridDim.x, ... (one 8-wave workgroup fits a CU; what a tile
+  // needs before its main loop is fetched during the previous tile's epilogue, its stores drain under the next main loop).
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; give each XCD one contiguous range of the
-  // (cout block major) tile list so that the U fragments of a cout block stay inside one L2
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  // (cout block major) tile list so that the U fragments of a cout block stay inside one L2 (gridDim.x is a multiple of 8
+  // whenever the tile count is, so a workgroup's tiles stay on its XCD's range).
   const int sp_tiles = g.tiles_w * g.tiles_h * p.B;
-  const int cb = bid / sp_tiles;
-  int sp = bid - cb * sp_tiles;
-  const int tw_i = sp % g.tiles_w;
-  sp /= g.tiles_w;
-  const int th_i = sp % g.tiles_h;
-  const int b0 = sp / g.tiles_h;                  // one image per tile
-  const int h0 = th_i * 16, w0 = tw_i * 16;
+  const int ntiles = ((p.Cout + WBN - 1) / WBN) * sp_tiles;
+  int cb = 0, tw_i = 0, th_i = 0, b0 = 0, h0 = 0, w0 = 0;
+  auto decode_tile = [&](int v) {
+    int bid = v;
+    if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
+    cb = (int)(((unsigned long long)(unsigned)bid * g.sp_magic) >> 32);     // bid / sp_tiles (host-side magic number)
+    int sp = bid - cb * sp_tiles;
+    if (g.pow2) {
+      tw_i = sp & (g.tiles_w - 1);
+      th_i = (sp >> g.log_tw) & (g.tiles_h - 1);
+      b0 = sp >> (g.log_tw + g.log_th);
+    } else {
+      tw_i = sp % g.tiles_w;
+      sp /= g.tiles_w;
+      th_i = sp % g.tiles_h;
+      b0 = sp / g.tiles_h;
+    }
+    h0 = th_i * 16; w0 = tw_i * 16;               // one image per tile
+  };
   constexpr int TWp = 18;
 
   const int nch = (Cin + WCK - 1) / WCK;
   const int cper = (nch + p.ksplit - 1) / p.ksplit;
   const int c_begin = blockIdx.y * cper;
   const int c_end = min(nch, c_begin + cper);
+  const int nck = c_end - c_begin;                // 1 .. W_MAX_CK (host)
+  const bool direct = p.ksplit == 1;
 
   // ---- raw staging items of this thread: item j covers halo pixel (tid >> 2) + 128 j, channel quad tid & 3 ----
+  // hinfo packs what is tile-independent: LDS float offset (bits 0..15), halo row (16..23), halo column (24..31); -1: no item
   const int kq = tid & 3, lrow = tid >> 2;
-  int hpix[WHI];
+  int hinfo[WHI], hpix[WHI];
 #pragma unroll
   for (int j = 0; j < WHI; ++j) {
     const int hp = lrow + (WNT / 4) * j;
-    int pix = -1;
+    hinfo[j] = -1;
+    hpix[j] = -1;
     if (hp < WHP) {
       const int hy = hp / TWp, hx = hp - hy * TWp;
-      const int ih = h0 + hy - 1, iw = w0 + hx - 1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        pix = (b0 * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+      hinfo[j] = (hy * WROW + ((hy >> 1) & 1) * WSHIFT + hx * WRS) | (hy << 16) | (hx << 24);
     }
-    hpix[j] = pix;
   }
-  f32x4 rh[WHI];
-  f32x4 ssa, ssb;           // scale/shift of this thread's channel quad
-  bool hvalid = false;
-  auto load_raw = [&](int chunk) {
+  auto set_pixels = [&]() {                       // source pixel of every staging item of the current tile (-1: zero padding)
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) {
+      const int hy = (hinfo[j] >> 16) & 0xff, hx = (hinfo[j] >> 24) & 0xff;
+      const int ih = h0 + hy - 1, iw = w0 + hx - 1;
+      const bool ok = hinfo[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+      hpix[j] = ok ? (b0 * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
+    }
+  };
+  f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
+  f32x4 rh2[WHI];           // ... of the tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
+  auto load_raw = [&](int chunk, f32x4 (&r)[WHI]) {
     const int c = chunk * WCK + kq * 4;
-    hvalid = c < Cin;
-    const int ce = hvalid ? c : 0;
+    const int ce = c < Cin ? c : 0;
     const bool second = ce >= p.C0;
     const float* sp_ = second ? p.src1 : p.src0;
     const int sC = second ? p.C1 : p.C0;
@@ -192,21 +235,26 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
       const int off = hpix[j] >= 0 ? hpix[j] * sC + cs : 0;
-      rh[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
+      r[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
     }
+  };
+  // GroupNorm (scale, shift) of the tile's image for the channels of this workgroup's chunk range live in LDS (cst + 64 of the
+  // tile's parity): the staging step reads its 4 channels' pairs from there instead of keeping 8 registers live across a chunk
+  auto store_raw = [&](float* raw, int chunk, const f32x4 (&r)[WHI], const float* cs_) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool hvalid = chunk * WCK + kq * 4 < Cin;
+    f32x4 ssa = zero, ssb = zero;
     if (p.act != 0) {
-      const float* q = p.ss + ((size_t)b0 * Cin + ce) * 2;
+      int kq_ = kq;
+      asm volatile("" : "+v"(kq_));
+      const float* q = cs_ + 64 + (chunk - c_begin) * (2 * WCK) + kq_ * 8;
       ssa = *reinterpret_cast<const f32x4*>(q);
       ssb = *reinterpret_cast<const f32x4*>(q + 4);
     }
-  };
-  auto store_raw = [&](float* raw) {
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
-      const int hp = lrow + (WNT / 4) * j;
-      if (hp < WHP) {
-        f32x4 v = rh[j];
+      if (lrow + (WNT / 4) * j < WHP) {
+        f32x4 v = r[j];
         if (p.act != 0 && !(DBG & 2)) {
           v.x = fmaf(v.x, ssa.x, ssa.y);
           v.y = fmaf(v.y, ssa.z, ssa.w);
@@ -215,8 +263,45 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           if (p.act == 2) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
-        *reinterpret_cast<f32x4*>(&raw[hp * WRS + kq * 4]) = v;
+        int hi = hinfo[j];
+        asm volatile("" : "+v"(hi));                // (the LDS address is derived here, not kept in a register of its own)
+        *reinterpret_cast<f32x4*>(&raw[(hi & 0xffff) + kq * 4]) = v;
       }
+    }
+  };
+  // Per-tile constants: bias + FiLM row of the tile's 64 output channels (cst[0..63]) and the (scale, shift) pairs of channels
+  // [16 c_begin, 16 c_end) (cst[64..]).  Two unconditional loads + two of pairs per thread (nck <= 64: host), then LDS.
+  const float* dummy = p.w;                          // valid memory for the loads of absent operands
+  f32x4 creg[4];
+  auto load_consts = [&]() {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));                     // (addresses recomputed per tile, not kept live across the main loop)
+    const int n = cb * WBN + (t_ & 15) * 4;
+    const int ne = n < p.Cout ? n : 0;
+    creg[0] = *reinterpret_cast<const f32x4*>((direct && p.bias ? p.bias : dummy) + ne);
+    creg[1] = *reinterpret_cast<const f32x4*>(direct && p.film ? p.film + (size_t)b0 * p.film_stride + ne : dummy);
+    const float* q = p.act != 0 ? p.ss + (size_t)b0 * Cin * 2 : dummy;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ch = c_begin * WCK + (t_ + WNT * k) * 2;         // 4 floats = 2 channels
+      creg[2 + k] = *reinterpret_cast<const f32x4*>(q + (p.act != 0 && ch < Cin ? (size_t)ch * 2 : 0));
+    }
+  };
+  auto store_consts = [&](float* cs_) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    if (t_ < 16) {
+      const int n = cb * WBN + t_ * 4;
+      f32x4 v = zero;
+      if (direct && n < p.Cout) v = (p.bias ? creg[0] : zero) + (p.film ? creg[1] : zero);
+      *reinterpret_cast<f32x4*>(cs_ + t_ * 4) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int e = t_ + WNT * k;
+      const int ch = c_begin * WCK + e * 2;
+      if (e < nck * (2 * WCK) / 4) *reinterpret_cast<f32x4*>(cs_ + 64 + e * 4) = (p.act != 0 && ch < Cin) ? creg[2 + k] : zero;
     }
   };
 
@@ -226,38 +311,41 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
   const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
   const float rsgn = (wi == 1) ? 1.f : -1.f;
-  // lane = tile (8 x 8 tiles of 2x2 outputs): float offset of the two patch rows this wave combines
-  const int ty = lane >> 3, tx = lane & 7;
-  const int offa = ((2 * ty + ra) * TWp + 2 * tx + wh) * WRS;
-  const int offb = ((2 * ty + rb) * TWp + 2 * tx + wh) * WRS;
-  const int rot = ty & 1;                           // per-lane channel-quad swap inside a half chunk: spreads the LDS banks
-  float* vw = vbase + wave * (2 * WT * WRS);        // this wave's two V planes [2][64][WRS]
-  // the transform of one channel quad, split so that its six LDS reads can be in flight across an MFMA block:
-  //   t_load issues the reads, t_finish does the row pass (3 FMAs), the column pass (2 adds) and the two LDS writes
-  auto t_load = [&](const float* rawbuf, int cq, f32x4 (&da)[3], f32x4 (&db)[3]) {
+  // Transform lanes: the 64 tiles are two blocks of 4 x 8 tiles (= the two 32-row MFMA blocks m); lane l works on tile
+  // l & 31 of the block and on channel quad 2 kk + (l >> 5) of the half chunk kk -- exactly the A operand layout of
+  // v_mfma_f32_32x32x2_f32 (row l & 31, k-half l >> 5), so the transformed values are MFMA operands as they are: V never
+  // goes through LDS.  Float offsets of the two patch rows this wave combines (tile block m = 1 is 8 rows further down:
+  // + 8 WROW, same shift parity -- an immediate offset of the read):
+  const int tl = lane & 31, hq = lane >> 5;
+  const int tyl = tl >> 3, tx = tl & 7;
+  const int r0 = 2 * tyl;
+  const int offa = (r0 + ra) * WROW + (((r0 + ra) >> 1) & 1) * WSHIFT + (2 * tx + wh) * WRS + hq * 4;
+  const int offb = (r0 + rb) * WROW + (((r0 + rb) >> 1) & 1) * WSHIFT + (2 * tx + wh) * WRS + hq * 4;
+  // the transform of one (m block, half chunk), split so that its six LDS reads can be in flight across an MFMA block:
+  //   t_load issues the reads, t_finish does the row pass (3 FMAs) and the column pass (2 adds): va / vb = this wave's two
+  //   positions, components = 4 consecutive k-steps
+  auto t_load = [&](const float* rawbuf, int m, int kk, f32x4 (&da)[3], f32x4 (&db)[3]) {
     if (DBG & 4) return;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + s * WRS + cq * 4);
-      db[s] = *reinterpret_cast<const f32x4*>(rawbuf + offb + s * WRS + cq * 4);
+      da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + (m * 8 * WROW + s * WRS + kk * 8));
+      db[s] = *reinterpret_cast<const f32x4*>(rawbuf + offb + (m * 8 * WROW + s * WRS + kk * 8));
     }
   };
-  auto t_finish = [&](int cq, const f32x4 (&da)[3], const f32x4 (&db)[3]) {
+  auto t_finish = [&](const f32x4 (&da)[3], const f32x4 (&db)[3], f32x4& va, f32x4& vb) {
     if (DBG & 4) return;
     f32x4 t[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) t[s] = da[s] + db[s] * rsgn;
     // wh == 0: columns j = 0, 1 from t0, t1, t2:  V0 = t0 - t2, V1 = t1 + t2
     // wh == 1: columns j = 2, 3 from t1, t2, t3:  V2 = t2 - t1, V3 = t1 - t3     (t[] = t1, t2, t3)
-    const f32x4 va = wh == 0 ? t[0] - t[2] : t[1] - t[0];
-    const f32x4 vb = wh == 0 ? t[1] + t[2] : t[0] - t[2];
-    *reinterpret_cast<f32x4*>(vw + (0 * WT + lane) * WRS + cq * 4) = va;
-    *reinterpret_cast<f32x4*>(vw + (1 * WT + lane) * WRS + cq * 4) = vb;
+    if (wh == 0) { va = t[0] - t[2]; vb = t[1] + t[2]; }
+    else { va = t[1] - t[0]; vb = t[0] - t[2]; }
   };
 
   // ---- U fragments: [pj][nblk][kk] float4, straight from global in fragment-major order ----
   f32x4 u[2][2][2];
-  const float* ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + lane * 4;
+  const float* ubase = nullptr;                     // set per tile (cout block)
   auto load_u = [&](int chunk, int kk) {             // the four fragments of half a chunk (channels 8 kk .. 8 kk + 7)
     if ((DBG & 16) && chunk != c_begin) return;
     const float* q = ubase + (size_t)chunk * 16 * 1024;
@@ -268,102 +356,62 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   };
 
   f32x16 acc[2][2][2];          // [pj][mblk][nblk]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
-  const int kh = (lane >> 5) * 4;
-  auto mfma_block = [&](int pj, int kk) {            // 16 MFMAs: this wave's position pj, channels 8 kk .. 8 kk + 7
-    f32x4 a[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-      a[m] = *reinterpret_cast<const f32x4*>(vw + (pj * WT + m * 32 + (lane & 31)) * WRS + kk * 8 + kh);
+  auto mfma_unit = [&](int m, int kk, const f32x4& va, const f32x4& vb) {   // 16 MFMAs: tile block m, channels 8 kk .. 8 kk + 7
     if (DBG & 1) {               // keep the operands live, issue no MFMA
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[pj][m][n][0] += a[m][0] * u[pj][n][kk][0];
+      for (int n = 0; n < 2; ++n) { acc[0][m][n][0] += va[0] * u[0][n][kk][0]; acc[1][m][n][0] += vb[0] * u[1][n][kk][0]; }
       return;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], u[pj][n][kk][q], acc[pj][m][n], 0, 0, 0);
+      for (int n = 0; n < 2; ++n) {
+        acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[q], u[0][n][kk][q], acc[0][m][n], 0, 0, 0);
+        acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[q], u[1][n][kk][q], acc[1][m][n], 0, 0, 0);
+      }
   };
 
-  // ---- main loop, software pipelined over half chunks -----------------------------------------------------------
-  // Chunk i's raw tile lives in raw[i & 1].  V holds channel quads {0,1} (kk = 0) and {2,3} (kk = 1) of both positions;
-  // a half is rebuilt for the NEXT use as soon as its two MFMA blocks are done, with the six LDS reads of every quad
-  // issued before an MFMA block and consumed after it:
-  //   block A(i): MFMA (pj 0|1, kk 0)   ||  transform half kk 1 of chunk i     (reads raw[i & 1])
-  //   barrier                               raw[i & 1] is free -> stage chunk i + 2 into it; chunk i + 1 is visible
-  //   block B(i): MFMA (pj 0|1, kk 1)   ||  transform half kk 0 of chunk i + 1 (reads raw[(i + 1) & 1])
-  const int nck = c_end - c_begin;
-  if (nck > 0) {
-    load_raw(c_begin);
-    store_raw(raw0);
-    if (nck > 1) { load_raw(c_begin + 1); store_raw(raw1); }
-    if (nck > 2) load_raw(c_begin + 2);
-    load_u(c_begin, 0);
-    load_u(c_begin, 1);
-    __syncthreads();
-    {
-      f32x4 da[3], db[3];
-      t_load(raw0, rot, da, db);
-      t_finish(rot, da, db);
-      t_load(raw0, rot ^ 1, da, db);
-      t_finish(rot ^ 1, da, db);
-    }
-    for (int i = 0; i < nck; ++i) {
-      float* rcur = (i & 1) ? raw1 : raw0;
-      const float* rnext = (i & 1) ? raw0 : raw1;
-      const bool more = i + 1 < nck;
-      f32x4 da[3], db[3];
-      // block A  (sched_barrier: keep the transform's LDS reads ahead of the MFMA block and its arithmetic behind it --
-      // left alone the scheduler sinks the reads below the MFMAs and waits on them at once)
-      t_load(rcur, 2 + rot, da, db);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_block(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      t_finish(2 + rot, da, db);
-      t_load(rcur, 2 + (rot ^ 1), da, db);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_block(1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      t_finish(2 + (rot ^ 1), da, db);
-      if (more) load_u(c_begin + i + 1, 0);
-      __syncthreads();
-      if (i + 2 < nck && !(DBG & 32)) {
-        store_raw(rcur);
-        if (i + 3 < nck) load_raw(c_begin + i + 3);
-      }
-      // block B
-      if (more) t_load(rnext, rot, da, db);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_block(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) { t_finish(rot, da, db); t_load(rnext, rot ^ 1, da, db); }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_block(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) { t_finish(rot ^ 1, da, db); load_u(c_begin + i + 1, 1); }
-    }
-  }
+  // DBG & 64: shader-clock stamps of the phases of every tile (lane 0 of every wave), 16 slots per (tile, wave), into
+  // ConvParams::partial
+  auto stamp = [&](int tile, int k) {
+    if ((DBG & 64) && lane == 0 && p.partial)
+      reinterpret_cast<unsigned long long*>(p.partial)[((size_t)tile * 8 + wave) * 16 + k] = __builtin_readcyclecounter();
+  };
 
-  // ---- epilogue -----------------------------------------------------------------------------------------------
-  // fold the two columns of this wave with A (A^T = [1 1 1 0; 0 1 -1 -1]):  P_q = sum_j M_ij A[j][q]
-  //   wh == 0 (j = 0, 1): P_0 = M0 + M1, P_1 = M1          wh == 1 (j = 2, 3): P_0 = M2, P_1 = -M2 - M3
-  // then Y[p][q] = sum_i A^T[p][i] (P_q(i,0) + P_q(i,1)) through LDS in a FIXED order, one 32-tile x 32-channel block
-  // per round (4 rounds).
-  if (DBG & 8) {                 // one store per thread keeps the accumulators live
-    float s = 0.f;
+#ifdef SR3_WINO_SETPRIO
+  // static priority for the second-dispatched half of the workgroup (the arbitration loser on every SIMD)
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  // ---- first tile: constants, raw chunks 0 and 1 ------------------------------------------------------------------
+  int vtile = blockIdx.x;
+  int par = 0;                                       // parity of the tile: which half of the constants block it uses
+  decode_tile(vtile);
+  set_pixels();
+  load_consts();
+  const int c1 = min(c_begin + 1, c_end - 1), c2 = min(c_begin + 2, c_end - 1);   // (short K ranges re-fetch their last chunk:
+  load_raw(c_begin, rh);                                                          //  the loads stay unconditional)
+  load_raw(c1, rh2);
+  store_consts(cst);
+  __syncthreads();
+
+  const int T = g.tiles_h * g.tiles_w;                             // statistics partials per image
+  const bool stats = direct && p.ostat != nullptr;
+  const bool has_res = direct && p.res0 != nullptr;
+  const size_t Mtot = (size_t)p.B * H * W;
+  float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
+  if (DBG & 64) dst = p.out;
+
+  for (;;) {
+    // ================================ prologue ================================
+    stamp(vtile, 0);
+    const float* cs_ = cst + par * W_CST_F;
+    {
+      int l_ = lane;
+      asm volatile("" : "+v"(l_));
+      ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + l_ * 4;
+    }
+    load_u(c_begin, 0);                               // L2 hits (every tile of the cout block reads them): back before the
+    load_u(c_begin, 1);                               // two staging steps below are done
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -371,106 +419,246 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s += acc[a][b][c][r];
-    p.out[(size_t)bid * WNT + tid] = s;
-    return;
-  }
-  __syncthreads();
-  float* exch = smem;                                              // [8 waves][2 q][32][WLDT]
-  double* part = reinterpret_cast<double*>(smem);                  // statistics: [512 threads][2 e][8], after the reads
-  const bool direct = p.ksplit == 1;
-  const bool stats = direct && p.ostat != nullptr;
-  const size_t Mtot = (size_t)p.B * H * W;
-  float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
-  // final-combine mapping: thread -> (p, q) sub-pixel of the 2x2 block, 16 tile rows x 8 channel quads, two tile halves e
-  const int pq = tid >> 7, fp = pq >> 1, fq = pq & 1;
-  const int ftile = (tid & 127) >> 3, fcq = tid & 7;
-  const int T = g.tiles_h * g.tiles_w;                             // statistics partials per image
-  const int tix = th_i * g.tiles_w + tw_i;
-  double s1[2][4], s2[2][4];                                       // this thread's channel quad of either 32-channel block
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s1[a][k] = 0.0; s2[a][k] = 0.0; }
-#pragma unroll
-  for (int nblk = 0; nblk < 2; ++nblk) {
-    const int n = cb * WBN + nblk * 32 + fcq * 4;
-    const bool nok = n < p.Cout;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (direct && nok && p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int mblk = 0; mblk < 2; ++mblk) {
-      f32x16 p0, p1;
-      if (wh == 0) {
-        p0 = acc[0][mblk][nblk] + acc[1][mblk][nblk];
-        p1 = acc[1][mblk][nblk];
-      } else {
-        p0 = acc[0][mblk][nblk];
-        p1 = -acc[0][mblk][nblk] - acc[1][mblk][nblk];
+          for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+    store_raw(raw0, c_begin, rh, cs_);
+    if (nck > 1) store_raw(raw1, c_begin + 1, rh2, cs_);
+    load_raw(c2, rh);
+    __syncthreads();
+    stamp(vtile, 1);
+
+    // ================================ main loop ================================
+    // A stream of units (m block, half chunk), software pipelined one unit deep.  Chunk i's raw tile lives in raw[i & 1].
+    // Unit order per chunk: (m0, kk0) (m1, kk0) (m0, kk1) (m1, kk1); the six LDS reads of a unit are issued before the
+    // PREVIOUS unit's MFMA block and consumed after it, its operands then stay in registers (va, vb) for its own block:
+    //   reads (m1,kk0)  | MFMA (m0,kk0) | finish (m1,kk0)
+    //   reads (m0,kk1)  | MFMA (m1,kk0) | finish (m0,kk1)        U fragments kk0 of chunk i + 1
+    //   reads (m1,kk1)  | MFMA (m0,kk1) | finish (m1,kk1)
+    //   barrier: raw[i & 1] is fully consumed -> stage chunk i + 2 into it; chunk i + 1's tile is visible
+    //   reads (m0,kk0) of chunk i + 1 | MFMA (m1,kk1) | finish    U fragments kk1 of chunk i + 1
+    {
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      {
+        f32x4 da[3], db[3];
+        t_load(raw0, 0, 0, da, db);
+        t_finish(da, db, va, vb);
       }
-      // D layout: reg r of lane l -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
-      float* e0 = exch + (wave * 2 + 0) * 32 * WLDT;
-      float* e1 = exch + (wave * 2 + 1) * 32 * WLDT;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        e0[row * WLDT + (lane & 31)] = p0[r];
-        e1[row * WLDT + (lane & 31)] = p1[r];
+      for (int i = 0; i < nck; ++i) {
+        float* rcur = (i & 1) ? raw1 : raw0;
+        const float* rnext = (i & 1) ? raw0 : raw1;
+        const bool more = i + 1 < nck;
+        f32x4 da[3], db[3];
+        // (sched_barrier: keep the next unit's LDS reads ahead of the MFMA block and its arithmetic behind it -- left
+        // alone the scheduler sinks the reads below the MFMAs and waits on them at once)
+        t_load(rcur, 1, 0, da, db);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(0, 0, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        t_finish(da, db, va, vb);
+        t_load(rcur, 0, 1, da, db);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(1, 0, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        t_finish(da, db, va, vb);
+        if (more) load_u(c_begin + i + 1, 0);
+        t_load(rcur, 1, 1, da, db);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(0, 1, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        t_finish(da, db, va, vb);
+        __syncthreads();
+        if (i + 2 < nck && !(DBG & 32)) {
+          store_raw(rcur, c_begin + i + 2, rh, cs_);
+          if (i + 3 < nck) load_raw(c_begin + i + 3, rh);
+        }
+        if (more) t_load(rnext, 0, 0, da, db);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_unit(1, 1, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { t_finish(da, db, va, vb); load_u(c_begin + i + 1, 1); }
       }
+    }
+
+    // ================================ epilogue ================================
+    // fold the two columns of this wave with A (A^T = [1 1 1 0; 0 1 -1 -1]):  P_q = sum_j M_ij A[j][q]
+    //   wh == 0 (j = 0, 1): P_0 = M0 + M1, P_1 = M1          wh == 1 (j = 2, 3): P_0 = M2, P_1 = -M2 - M3
+    // then Y[p][q] = sum_i A^T[p][i] (P_q(i,0) + P_q(i,1)) through LDS in a FIXED order (bitwise reproducible), one 32-channel
+    // block per round.  Exchange layout: plane (wave, q) = [32 channels][64 tiles + 4 pad], channels >= 16 shifted by 4 floats
+    // more, so that both the 16-byte writes (8 consecutive channels per lane group) and the 16-byte reads are bank-conflict
+    // free; thread -> (sub-pixel p q, 4 consecutive tiles, 4 consecutive channels): 24 reads of 4 tiles each, a 4 x 4
+    // register transpose, 4 NHWC stores of 16 bytes (8 adjacent lanes = 128 contiguous bytes).
+    // Lane roles: thread -> (sub-pixel p q, 4 consecutive tiles, 4 consecutive channels).  The lane id is laundered through an
+    // empty asm so that this index arithmetic is redone per tile instead of being hoisted out of the tile loop, where it would
+    // occupy registers -- or scratch, whose reloads drain the memory queue -- across the main loop.
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int etid = wave * 64 + elane;
+    const int nq = elane & 7, fq = (elane >> 4) & 1, fp = wave >> 2;
+    const int tq = ((elane >> 5) & 1) | (((elane >> 3) & 1) << 1) | ((wave & 3) << 2);   // tiles 4 tq .. 4 tq + 3 (half a tile row)
+    const int ety = tq >> 1, etx0 = (tq & 1) * 4;                                       // tile row, first tile column
+    const int e_cb = cb, e_b0 = b0, e_tix = th_i * g.tiles_w + tw_i, e_vtile = vtile;
+    const size_t pix0 = ((size_t)b0 * H + (h0 + 2 * ety + fp)) * W + (w0 + 2 * etx0 + fq);   // tile k of the four: + 2 k pixels
+    stamp(e_vtile, 2);
+    // the next tile (the last one re-fetches itself: the loads stay unconditional)
+    const bool has_next = vtile + (int)gridDim.x < ntiles;
+    if (has_next) vtile += gridDim.x;
+    // this tile's residual, both rounds: 8 loads (absent: a valid dummy address, discarded below)
+    f32x4 addv[2][4];
+#pragma unroll
+    for (int nblk = 0; nblk < 2; ++nblk) {
+      const int n = e_cb * WBN + nblk * 32 + nq * 4;
+      const int ne = n < p.Cout ? n : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const size_t pix = pix0 + 2 * k;
+        const float* rp = dst + pix * p.Cout + ne;
+        if (has_res) rp = (ne < p.RC0) ? p.res0 + pix * p.RC0 + ne : p.res1 + pix * p.RC1 + (ne - p.RC0);
+        addv[nblk][k] = *reinterpret_cast<const f32x4*>(rp);
+      }
+    }
+    if (DBG & 8) {                 // one store per thread keeps the accumulators live
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[a][b][c][r];
+      p.out[(size_t)e_vtile * WNT + etid] = s + addv[0][0][0] + addv[1][3][3];
       __syncthreads();
+      decode_tile(vtile);
+      load_consts();
+      store_consts(cst + (par ^ 1) * W_CST_F);
+      set_pixels();
+      load_raw(c_begin, rh);
+      load_raw(c1, rh2);
+      __syncthreads();
+      par ^= 1;
+      if (!has_next) break;
+      continue;
+    }
+    // bias + FiLM of this thread's two channel quads (LDS: written a tile ago)
+    f32x4 base[2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int trow = ftile + 16 * e;                 // tile row inside this 32-tile block
-        auto rd = [&](int i, int hh) {
-          return *reinterpret_cast<const f32x4*>(exch + (((i * 2 + hh) * 2 + fq) * 32 + trow) * WLDT + fcq * 4);
-        };
-        const f32x4 r0 = rd(0, 0) + rd(0, 1), r1 = rd(1, 0) + rd(1, 1), r2 = rd(2, 0) + rd(2, 1), r3 = rd(3, 0) + rd(3, 1);
-        f32x4 v = fp == 0 ? (r0 + r1) + r2 : (r1 - r2) - r3;
-        const int tau = mblk * 32 + trow;                // tile of the 8 x 8 grid
-        const int ty = tau >> 3, tx = tau & 7;
-        const int b = b0;
-        if (b < p.B && nok) {
-          const size_t pix = ((size_t)b * H + (h0 + 2 * ty + fp)) * W + (w0 + 2 * tx + fq);
-          if (direct) {
-            v += bias4;
-            if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
-            if (p.res0) {
-              if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + pix * p.RC0 + n);
-              else v += *reinterpret_cast<const f32x4*>(p.res1 + pix * p.RC1 + (n - p.RC0));
-            }
-            if (stats) {
+    for (int nblk = 0; nblk < 2; ++nblk) base[nblk] = *reinterpret_cast<const f32x4*>(cs_ + nblk * 32 + nq * 4);
+    stamp(e_vtile, 3);
+    __syncthreads();                                                 // the raw tiles are dead: the exchange block reuses LDS
+    stamp(e_vtile, 4);
+    float* exch = smem;                                              // [8 waves][2 q][WEPL]
+    double* part = reinterpret_cast<double*>(smem);                  // statistics parking (after the last round)
+    double s1[2][4], s2[2][4];                                       // this thread's channel quad of either 32-channel block
 #pragma unroll
-              for (int k = 0; k < 4; ++k) { const double dv = (double)v[k]; s1[nblk][k] += dv; s2[nblk][k] += dv * dv; }
-            }
-          }
-          *reinterpret_cast<f32x4*>(dst + pix * p.Cout + n) = v;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s1[a][k] = 0.0; s2[a][k] = 0.0; }
+    const int wn = elane & 31;                                       // channel this lane's accumulator column belongs to
+    float* wbase = exch + (wave * 2) * WEPL + wn * WETS + (wn >> 4) * 4 + 4 * (elane >> 5);
+#pragma unroll
+    for (int nblk = 0; nblk < 2; ++nblk) {
+      const int n = e_cb * WBN + nblk * 32 + nq * 4;
+      const bool nok = n < p.Cout;
+#pragma unroll
+      for (int mblk = 0; mblk < 2; ++mblk) {
+        f32x16 p0, p1;
+        if (wh == 0) {
+          p0 = acc[0][mblk][nblk] + acc[1][mblk][nblk];
+          p1 = acc[1][mblk][nblk];
+        } else {
+          p0 = acc[0][mblk][nblk];
+          p1 = -acc[0][mblk][nblk] - acc[1][mblk][nblk];
+        }
+        // D layout: reg r of lane l -> tile (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the block, channel l & 31
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          *reinterpret_cast<f32x4*>(wbase + mblk * 32 + 8 * k) = f32x4{p0[4 * k], p0[4 * k + 1], p0[4 * k + 2], p0[4 * k + 3]};
+          *reinterpret_cast<f32x4*>(wbase + WEPL + mblk * 32 + 8 * k) = f32x4{p1[4 * k], p1[4 * k + 1], p1[4 * k + 2], p1[4 * k + 3]};
         }
       }
+      stamp(e_vtile, 5 + 4 * nblk);
+      if (nblk == 0) {
+        // half of the accumulators are dead: the next tile's constants (4 loads) and raw chunks 0 and 1 are put in flight
+        decode_tile(vtile);
+        load_consts();
+        set_pixels();
+        load_raw(c_begin, rh);
+        load_raw(c1, rh2);
+      }
+      stamp(e_vtile, 6 + 4 * nblk);
+      __syncthreads();
+      stamp(e_vtile, 7 + 4 * nblk);
+      {
+        // Y[p][q] = sum_i A^T[p][i] (P_q(i, 0) + P_q(i, 1)), rows in a fixed order: p = 0: (r0 + r1) + r2, p = 1: (r1 - r2) - r3
+        f32x4 y[4];                                                  // [channel j] over the 4 tiles
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nn = nq * 4 + j;
+          const float* rb_ = exch + nn * WETS + (nn >> 4) * 4 + 4 * tq;
+          auto rd = [&](int i) {
+            return *reinterpret_cast<const f32x4*>(rb_ + ((i * 2 + 0) * 2 + fq) * WEPL) +
+                   *reinterpret_cast<const f32x4*>(rb_ + ((i * 2 + 1) * 2 + fq) * WEPL);
+          };
+          if (fp == 0) { const f32x4 r0_ = rd(0), r1_ = rd(1), r2_ = rd(2); y[j] = (r0_ + r1_) + r2_; }
+          else { const f32x4 r1_ = rd(1), r2_ = rd(2), r3_ = rd(3); y[j] = (r1_ - r2_) - r3_; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 v = f32x4{y[0][k], y[1][k], y[2][k], y[3][k]};
+          if (direct) {
+            v += base[nblk];
+            if (has_res) v += addv[nblk][k];
+            if (stats) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) { const double dv = (double)v[c]; s1[nblk][c] += dv; s2[nblk][c] += dv * dv; }
+            }
+          }
+          if (nok) *reinterpret_cast<f32x4*>(dst + (pix0 + 2 * k) * p.Cout + n) = v;
+        }
+      }
+      if (nblk == 0) store_consts(cst + (par ^ 1) * W_CST_F);      // ... and the constants go to LDS (the other parity)
+      stamp(e_vtile, 8 + 4 * nblk);
       __syncthreads();                                  // every read of the exchange block is complete
     }
-  }
-  if (stats) {
-    // Per-channel sums of this tile's outputs (one image per tile), reduced once, in a fixed order: every thread parks the
-    // sums of its two channel quads (one per 32-channel block) in the now free exchange region, then one thread per
-    // (channel, sum) walks the 64 threads (4 sub-pixels x 16 tile rows) that share its channel quad.
+    stamp(e_vtile, 13);
+    if (stats) {
+      // Per-channel sums of this tile's outputs (one image per tile), in a fixed order, as a two-level tree over LDS: every
+      // thread parks its 16 partial sums e = [sum | sum of squares][32-channel block][channel of the quad] as part[e][thread]
+      // (rows of 520 doubles: consecutive lanes write consecutive doubles, and the 4 rows a 32-lane group reads below sit 16
+      // banks apart -- the thread-major layout cost 8 k cycles of bank conflicts per tile); 512 threads each add 16 of the 64
+      // partials that share a channel quad (threads nq, nq + 8, ...), 128 threads add the 4 results.
+      constexpr int PR = 520;
 #pragma unroll
-    for (int nb2 = 0; nb2 < 2; ++nb2)
+      for (int nb2 = 0; nb2 < 2; ++nb2)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { part[(tid * 2 + nb2) * 8 + k] = s1[nb2][k]; part[(tid * 2 + nb2) * 8 + 4 + k] = s2[nb2][k]; }
-    __syncthreads();
-    if (tid < 128) {
-      const int c = tid & 63, which = tid >> 6;              // channel of the 64-wide block, 0 = sum | 1 = sum of squares
-      const int nb2 = c >> 5, cq = (c & 31) >> 2, k = c & 3;
-      double a = 0.0;
-#pragma unroll 8
-      for (int src = 0; src < 64; ++src) {
-        const int t = (src >> 4) * 128 + (src & 15) * 8 + cq;
-        a += part[(t * 2 + nb2) * 8 + which * 4 + k];
+        for (int k = 0; k < 4; ++k) {
+          part[(nb2 * 4 + k) * PR + etid] = s1[nb2][k];
+          part[(8 + nb2 * 4 + k) * PR + etid] = s2[nb2][k];
+        }
+      __syncthreads();
+      {
+        const int cq = etid & 7, e = (etid >> 3) & 15, grp = etid >> 7;
+        double a = 0.0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a += part[e * PR + (grp * 16 + s) * 8 + cq];
+        part[16 * PR + grp * 128 + e * 8 + cq] = a;
       }
-      const int nn = cb * WBN + c;
-      if (nn < p.Cout) p.ostat[(((size_t)b0 * T + tix) * p.Cout + nn) * 2 + which] = a;
+      __syncthreads();
+      stamp(e_vtile, 14);
+      if (etid < 128) {
+        const int cq = etid & 7, e = etid >> 3;                   // e = which * 8 + nb2 * 4 + k
+        double a = part[16 * PR + etid];
+#pragma unroll
+        for (int grp = 1; grp < 4; ++grp) a += part[16 * PR + grp * 128 + etid];
+        const int which = e >> 3, c = ((e >> 2) & 1) * 32 + cq * 4 + (e & 3);
+        const int nn = e_cb * WBN + c;
+        if (nn < p.Cout) p.ostat[(((size_t)e_b0 * T + e_tix) * p.Cout + nn) * 2 + which] = a;
+      }
     }
-  }
+    __syncthreads();                                    // LDS (exchange block / parked sums) is free for the next tile
+    stamp(e_vtile, 15);
+    par ^= 1;
+    if (!has_next) break;
+  }   // tile loop
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------
@@ -489,6 +677,12 @@ bool wino_geometry(const ConvParams& p, WinoGeom* g) {
   g->tiles_w = W / 16; g->tiles_h = H / 16;
   g->HPI = WHP;
   g->HP = WHP;
+  // tile decode of the persistent kernel: shifts when the tile grid is a power of two, a magic number for / sp_tiles
+  g->log_tw = ilog2x(g->tiles_w); g->log_th = ilog2x(g->tiles_h);
+  g->pow2 = ((1 << g->log_tw) == g->tiles_w && (1 << g->log_th) == g->tiles_h) ? 1 : 0;
+  const unsigned long long spt = (unsigned long long)g->tiles_w * g->tiles_h * p.B;
+  if (spt == 0 || spt * spt * ((p.Cout + WBN - 1) / WBN) >= (1ull << 32)) return false;    // (keeps the multiply-high exact)
+  g->sp_magic = (unsigned)(((1ull << 32) + spt - 1) / spt);
   return true;
 }
 int wino_stats_slices(const WinoGeom& g) { return g.tiles_h * g.tiles_w; }
@@ -503,8 +697,17 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (!ufrag) { set_error("conv: Winograd needs the transformed weights"); return SR3_E_BADARG; }
   if (p.x2_w || p.drop_thresh != 0) { set_error("conv: the Winograd kernel has no fused 1x1 segment / dropout form"); return SR3_E_UNSUPPORTED; }
   const int nch = wino_chunks(p);
+  if ((nch + p.ksplit - 1) / p.ksplit > W_MAX_CK) { set_error("conv: the Winograd kernel takes at most %d input channels per K split (%d chunks over %d splits)", W_MAX_CK * WCK, nch, p.ksplit); return SR3_E_UNSUPPORTED; }
   if (p.ksplit > 1 && (long)(p.ksplit - 1) * ((nch + p.ksplit - 1) / p.ksplit) >= nch) { set_error("conv: ksplit %d leaves an empty split over %d chunks", p.ksplit, nch); return SR3_E_BADARG; }
-  dim3 grid((unsigned)wino_workgroups(p, g), p.ksplit);
+  // persistent workgroups: one per CU (8 waves, 157 KB of LDS), each walking its share of the tile list
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n & ~7;               // a multiple of 8 keeps every workgroup's tiles on one XCD's range of the list
+  }();
+  const long ntiles = wino_workgroups(p, g);
+  const char* np = getenv("SR3_WINO_NONPERSISTENT");
+  dim3 grid((unsigned)((np && np[0] == '1') ? ntiles : std::min<long>(ntiles, n_cu > 0 ? n_cu : 256)), p.ksplit);
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
 #define SR3_WINO_LAUNCH(D)                                                                                   \
   {                                                                                                          \
@@ -524,6 +727,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
     case 38: SR3_WINO_LAUNCH(38) break;       // MFMA + U + epilogue only
     case 46: SR3_WINO_LAUNCH(46) break;       // MFMA + U only
     case 62: SR3_WINO_LAUNCH(62) break;       // bare MFMA loop
+    case 64: SR3_WINO_LAUNCH(64) break;       // phase time stamps
 #endif
     default: set_error("conv: SR3_WINO_DBG=%d is not built (compile with -DSR3_WINO_ABLATIONS)", dbg); return SR3_E_BADARG;
   }

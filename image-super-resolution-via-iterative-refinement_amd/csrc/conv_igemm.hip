@@ -380,7 +380,8 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       if (ks > cap) ks = cap;
       if (ks > 16) ks = 16;
     }
-    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;
+    if (cdiv(units, ks) > 64) ks = cdiv(units, 64);        // at most 64 chunks (1024 input channels) per split: the kernel's
+    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;   // LDS block of GroupNorm pairs
     ksplit = ks;
     return;
   }

@@ -1137,6 +1137,10 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
     const int rc = wino_transform_weights(w, Cout, c.C0 + c.C1, u, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     c.wino_u = u;
+#ifdef SR3_WINO_ABLATIONS
+    // tooling build only: room behind the filters for the kernel's phase time stamps (SR3_WINO_DBG=64, tools/wino_phases.py)
+    if (scratch_bytes >= slab + ub + (1u << 20)) c.partial = reinterpret_cast<float*>(reinterpret_cast<char*>(u) + ub);
+#endif
     scratch_bytes = slab;
   }
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));

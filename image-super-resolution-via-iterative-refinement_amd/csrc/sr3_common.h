@@ -146,6 +146,8 @@ struct WinoGeom {
   int tpi, log_tpi;      // Winograd tiles per image of the workgroup tile
   int tiles_w, tiles_h;  // workgroup tiles per image
   int HPI, HP;           // raw halo pixels per image / per workgroup
+  int log_tw, log_th, pow2;   // tile decode of the persistent kernel: tiles_w / tiles_h as shifts when both are powers of two
+  unsigned sp_magic;          // ceil(2^32 / (tiles_w * tiles_h * B)): tile id / tiles-per-cout-block as a multiply-high
 };
 bool wino_geometry(const ConvParams& p, WinoGeom* g);
 int wino_stats_slices(const WinoGeom& g);

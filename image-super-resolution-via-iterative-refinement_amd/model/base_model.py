@@ -26,7 +26,7 @@ class BaseModel(object):
         _, world, local = _dist.bootstrap()
         if opt['gpu_ids'] is None:
             self.device = torch.device('cpu')
-        elif world > 1 and torch.cuda.is_available():
+        elif _dist.dp_active() and torch.cuda.is_available():
             self.device = torch.device('cuda', local)
         else:
             self.device = torch.device('cuda')
