@@ -43,7 +43,7 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-PROFILE_ROUND = 'r02'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
+PROFILE_ROUND = 'r03'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
 
 # The `model` subtrees of the reference's configs (config/sr_sr3_16_128.json:39-77, sr_sr3_64_512.json:39-80,
 # sample_ddpm_128.json:38-79) + the batch sizes BASELINE.json quotes.
@@ -363,18 +363,39 @@ def roofline_from_profile(netG, x, cond, reps=3):
     is_split = (not is_wino) and names[dom].split(',')[4] == '1'
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
-    extra = {}
-    if is_wino:
-        # Winograd F(2x2,3x3): 16 multiplies per 2x2 output block and (cin, cout) pair instead of 36.  `achieved` stays
-        # the ALGORITHMIC (direct-convolution) FLOP rate SURVEY.md 8d defines, so it may exceed the MFMA peak; the MFMA
-        # pipe itself executes 1/2.25 of those FLOPs: `executed_*` is the fraction of the fp32 MFMA roof the kernel runs at.
-        extra = dict(executed_mfma_tflops=achieved / 2.25, executed_frac=achieved / 2.25 / peak,
-                     note='Winograd F(2x2,3x3): frac = algorithmic (direct-conv) FLOP/s / fp32 MFMA peak, can exceed 1; '
-                          'executed_frac = MFMA FLOPs actually issued (algorithmic / 2.25) / peak')
+    # Winograd F(2x2,3x3): 16 multiplies per 2x2 output block and (cin, cout) pair instead of 36, so the MFMA pipe executes
+    # 1 / 2.25 of the direct-convolution FLOPs SURVEY.md 8d counts.  `achieved` / `frac` are the EXECUTED MFMA rate against the
+    # fp32 MFMA roof (a fraction of a roof, <= 1); the direct-convolution-equivalent rate is reported beside it.
+    executed = achieved / 2.25 if is_wino else achieved
+    # step level: the floor the design chose = (Winograd FLOPs / 2.25 + all other contraction FLOPs) / peak
+    wino_fl = agg[455][1] / reps if 455 in agg else 0.0
+    all_fl = sum(a[1] for a in agg.values()) / reps
+    floor_ms = (wino_fl / 2.25 + (all_fl - wino_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    # algorithmic HBM bytes of the dominant kernel's launches (each input / residual / output tensor and the transformed
+    # filters once per launch), from the plan's own launch list
+    alg_bytes = None
+    try:
+        ops = [o for o in plan.op_list(B) if o['kind'] == 5 and o['tile_cfg'] == 11] if is_wino else []
+        if ops:
+            tot = 0.0
+            for o in ops:
+                px = B * o['h_out'] * o['w_out']
+                src_px = px // (4 if o['upsample'] else 1)
+                tot += 4.0 * (src_px * o['cin'] + px * o['cout'] + 16.0 * o['cin'] * o['cout'])
+            alg_bytes = tot / len(ops)
+    except Exception:
+        pass
+    extra = dict(direct_equiv_tflops=achieved, executed_mfma_tflops=executed,
+                 step_floor_ms_at_fp32_mfma_peak=floor_ms, launches_ms_per_forward=total_ms,
+                 step_frac_of_winograd_roof=(floor_ms / total_ms if total_ms > 0 else None),
+                 algorithmic_bytes_per_launch=alg_bytes,
+                 traffic_over_algorithmic=(traffic / alg_bytes if traffic and alg_bytes else None),
+                 note='achieved / frac = MFMA FLOPs actually issued (direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) vs the fp32 '
+                      'MFMA peak; direct_equiv_tflops = SURVEY 8d algorithmic FLOPs / time (can exceed the peak)')
     return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
-                                                   else (' (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)' if is_wino
-                                                         else ' (v_mfma_f32_32x32x2_f32)')), achieved=achieved,
-                peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic, **extra,
+                                                   else (' (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, persistent workgroups)' if is_wino
+                                                         else ' (v_mfma_f32_32x32x2_f32)')), achieved=executed,
+                peak=peak, unit='TFLOP/s', frac=executed / peak, traffic=traffic, **extra,
                 traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/%s_bench_hbm_pmc.csv'
                              % PROFILE_ROUND,
                 avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,
@@ -432,7 +453,7 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
     import model as Model
     c = CONFIGS[cfg_name]
     opt = config_opt(cfg_name, phase='train')
-    torch.manual_seed(0)
+    torch.manual_seed(1000 + rank)              # per-rank streams (z, dropout seed, data); create_model broadcasts rank 0's weights
     np.random.seed(1234 + rank)
     m = Model.create_model(opt)
     S = c['size']
@@ -468,6 +489,102 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
 
 
+def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000):
+    """define_G of a BASELINE.json network (random init, seed 0), its reverse-step hipGraph captured at batch B."""
+    import torch
+    import model.networks as networks
+    cfg = CONFIGS[cfg_name]
+    torch.manual_seed(0)
+    opt = config_opt(cfg_name, T)
+    netG = networks.define_G(opt).to(dev)
+    netG.set_loss(dev)
+    netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], dev)
+    netG.eval()
+    netG.denoise_fn.plan.set_option('fuse_stats', 1)
+    if split_bf16:
+        netG.denoise_fn.plan.set_option('split_bf16', 1)
+    S = cfg['size']
+    torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
+    shape = (B, 3, S, S)
+    st = netG._loop_state(shape, shape if cfg['conditional'] else None, dev)
+    if cfg['conditional']:
+        st['cond'].copy_(torch.rand(shape, device=dev) * 2 - 1)
+    st['img'].copy_(torch.randn(shape, device=dev))
+    st['step'].fill_(T - 1)
+    netG._capture(st)
+    return netG, st
+
+
+def time_replays(st, steps, warmup, T, dist, dev):
+    """W untimed + exactly K timed graph replays (chains of T steps), barrier + synchronize on both sides, MAX over ranks."""
+    import torch
+    graph = st['graph']
+    st['step'].fill_(T - 1)
+    for _ in range(warmup):
+        graph.replay()
+    st['step'].fill_(T - 1)
+    st['img'].normal_()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps:                                   # exactly K steps, chains of T
+        n = min(steps - done, T)
+        for _ in range(n):
+            graph.replay()
+        done += n
+        if done < steps:
+            st['step'].fill_(T - 1)
+            st['img'].normal_()
+    torch.cuda.synchronize(dev)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def other_config_leg(cfg_name, dev, steps=50, warmup=3, T=2000):
+    """A bounded run of another BASELINE.json configuration (configs[3] SR3 64->512 at batch 4, configs[4] DDPM-128 at batch 32)
+    for the driver's record: graph-replayed reverse steps, the parity of that graph against the CPU oracle, and the dominant
+    kernel's executed-MFMA fraction.  Rank 0, N = 1 only; not part of `value`."""
+    import torch
+    cfg = CONFIGS[cfg_name]
+    B = cfg['batch']
+    netG, st = build_sampler(cfg_name, B, dev, 0)
+    elapsed = time_replays(st, steps, warmup, T, None, dev)
+    ms = elapsed / steps * 1e3
+    out = {'metric': '%s images/sec (2000-step sample)' % cfg['title'], 'value': B / (T * ms * 1e-3), 'unit': 'images/s',
+           'ms_per_step': ms, 'steps': steps, 'warmup': warmup, 'batch': B,
+           'workload': '%s UNet (reference %s; BASELINE.json configs[%d]), batch %d, hipGraph-replayed reverse steps'
+                       % (cfg['title'], cfg['ref_json'], cfg['baseline_cfg'], B),
+           'output_finite': bool(torch.isfinite(st['img']).all().item())}
+    try:
+        par = capture_parity_inputs(netG, st, cfg, T)
+        rec, _, _ = parity_vs_oracle(cfg_name, netG, par)
+        out['parity_max_abs'] = rec['parity_max_abs']
+        out['parity_ok'] = rec['ok']
+    except Exception as e:
+        out['parity_error'] = '%s: %s' % (type(e).__name__, e)
+    try:
+        rf = roofline_from_profile(netG, st['img'], st['cond'], reps=2)
+        out['roofline'] = {k: rf[k] for k in ('kernel', 'achieved', 'peak', 'frac', 'direct_equiv_tflops', 'avg_launch_us',
+                                             'launches_per_forward', 'share_of_forward_time', 'step_frac_of_winograd_roof')}
+    except Exception as e:
+        out['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    st['graph'] = None
+    netG._loop_cache = {}
+    del netG, st
+    torch.cuda.empty_cache()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # launcher
 # ---------------------------------------------------------------------------------------------------------------
@@ -500,6 +617,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-torch-baseline', action='store_true', help='skip the stock PyTorch-ROCm (MIOpen) leg')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the bounded legs of the other BASELINE.json configurations (SR3 64->512 batch 4, DDPM-128 batch 32)')
     ap.add_argument('--no-split-leg', action='store_true', help='(default now) skip the secondary split_bf16 measurement')
     ap.add_argument('--split-leg', action='store_true',
                     help='also time the opt-in split_bf16 plan option (direct halo kernels on bf16 MFMA; superseded by the fp32 '
@@ -509,7 +628,7 @@ def main():
                          '"f32 via 3xbf16 split MFMA"; the default is the exact-fp32 MFMA path)')
     ap.add_argument('--train-steps', type=int, default=10, help='0 disables the training leg')
     ap.add_argument('--train-batch', type=int, default=0, help='images per GPU (default: the BASELINE.json batch of --config)')
-    ap.add_argument('--extra-leg-timeout', type=int, default=480,
+    ap.add_argument('--extra-leg-timeout', type=int, default=600,
                     help='seconds after which the roofline / split / train / baseline legs are abandoned and the line is printed')
     a = ap.parse_args()
 
@@ -529,68 +648,33 @@ def main():
     if torch.cuda.device_count() <= local:
         sys.stderr.write('bench.py: rank %d needs cuda:%d but %d device(s) are visible\n' % (rank, local, torch.cuda.device_count()))
         sys.exit(2)
-    torch.cuda.set_device(local)              # before the process group: RCCL binds its communicator to the current device
-    dev = torch.device('cuda', local)
-    dist = None
-    if world > 1 or os.environ.get('SR3_BENCH_FORCE_DIST'):     # the env knob exercises the collective path on one GPU
-        import torch.distributed as dist
+    # Joining the job is the drop-in's own code path (sr3_hip.dist.bootstrap: cuda:LOCAL_RANK, RCCL group bound to it, per-rank
+    # RNG) -- the one `model.create_model` / `data.create_dataloader` take under torch.distributed.run
+    if os.environ.get('SR3_BENCH_FORCE_DIST'):              # the env knob exercises the collective path on one GPU
+        os.environ.setdefault('SR3_DP', 'force')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('RANK', '0')
+    if world > 1 or os.environ.get('SR3_BENCH_FORCE_DIST'):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    from sr3_hip import dist as D
+    b_rank, b_world, b_local = D.bootstrap()
+    if world > 1 and (b_rank, b_world, b_local) != (rank, world, local):
+        sys.stderr.write('bench.py: bootstrap gave rank %d/%d local %d, the launcher said %d/%d local %d\n'
+                         % (b_rank, b_world, b_local, rank, world, local))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if D.dp_active():
+        import torch.distributed as dist
 
-    import model.networks as networks
     cfg = CONFIGS[a.config]
     T = 2000
-    torch.manual_seed(0)
-    opt = config_opt(a.config, T)
-    netG = networks.define_G(opt).to(dev)
-    netG.set_loss(dev)
-    netG.set_new_noise_schedule(opt['model']['beta_schedule']['val'], dev)
-    netG.eval()
-    netG.denoise_fn.plan.set_option('fuse_stats', 1)
-    if a.split_bf16:
-        netG.denoise_fn.plan.set_option('split_bf16', 1)
     B = a.batch or cfg['batch']
     S = cfg['size']
-    torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
-    shape = (B, 3, S, S)
-    st = netG._loop_state(shape, shape if cfg['conditional'] else None, dev)
-    if cfg['conditional']:
-        st['cond'].copy_(torch.rand(shape, device=dev) * 2 - 1)
-    st['img'].copy_(torch.randn(shape, device=dev))
-    st['step'].fill_(T - 1)
-    netG._capture(st)
-    graph = st['graph']
-
-    st['step'].fill_(T - 1)
-    # warm-up
-    for _ in range(a.warmup):
-        graph.replay()
-    st['step'].fill_(T - 1)
-    st['img'].normal_()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    done = 0
-    while done < a.steps:                                 # exactly K steps, chains of T
-        n = min(a.steps - done, T)
-        for _ in range(n):
-            graph.replay()
-        done += n
-        if done < a.steps:
-            st['step'].fill_(T - 1)
-            st['img'].normal_()
-    torch.cuda.synchronize(dev)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    netG, st = build_sampler(a.config, B, dev, rank, a.split_bf16, T)
+    elapsed = time_replays(st, a.steps, a.warmup, T, dist, dev)
     finite = bool(torch.isfinite(st['img']).all().item())
     ms_per_step = elapsed / a.steps * 1e3
     images_per_s = world * B / (T * ms_per_step * 1e-3)
@@ -609,8 +693,7 @@ def main():
                    'name': a.config, 'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': S,
                    'params': nparams, 'parallelism': 'independent batches per rank (no collective)',
                    'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
-        'step_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,
-        'step_frac_of_fp32_mfma_peak': flops_step / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        'step_direct_equiv_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,     # SURVEY 8d FLOPs / time (Winograd executes fewer)
         'parity_max_abs': None,
     }
     printed = threading.Lock()
@@ -649,7 +732,6 @@ def main():
             rec['split_bf16'] = {'error': '%s: %s' % (type(e).__name__, e)}
     # free the sampling state (graph, workspace) -- the training workspace is ~18 GB at batch 64
     st['graph'] = None
-    graph = None
     netG._loop_cache = {}
     torch.cuda.empty_cache()
     if a.train_steps > 0:
@@ -675,6 +757,15 @@ def main():
             rec['torch_rocm_baseline'] = torch_rocm_baseline(a.config, netG, par, dev)
         except Exception as e:
             rec['torch_rocm_baseline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0 and world == 1 and a.config == 'sr3_16_128' and not a.no_other_configs:
+        # the other BASELINE.json configurations, bounded (50 replayed steps each), so that they are in the driver's record too
+        rec['other_configs'] = {}
+        for name in ('sr3_64_512', 'ddpm_128'):
+            try:
+                rec['other_configs'][name] = other_config_leg(name, dev)
+            except Exception as e:
+                rec['other_configs'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     timer.cancel()
     emit()
     if dist:

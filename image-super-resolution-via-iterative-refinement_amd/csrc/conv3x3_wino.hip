@@ -177,7 +177,8 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   auto decode_tile = [&](int v) {
     int bid = v;
     if ((ntiles & 7) == 0) bid = (bid & 7) * (ntiles >> 3) + (bid >> 3);
-    cb = (int)(((unsigned long long)(unsigned)bid * g.sp_magic) >> 32);     // bid / sp_tiles (host-side magic number)
+    // bid / sp_tiles by a host-side magic number (0: one tile per cout block, the quotient is bid itself)
+    cb = g.sp_magic ? (int)(((unsigned long long)(unsigned)bid * g.sp_magic) >> 32) : bid;
     int sp = bid - cb * sp_tiles;
     if (g.pow2) {
       tw_i = sp & (g.tiles_w - 1);
@@ -682,7 +683,7 @@ bool wino_geometry(const ConvParams& p, WinoGeom* g) {
   g->pow2 = ((1 << g->log_tw) == g->tiles_w && (1 << g->log_th) == g->tiles_h) ? 1 : 0;
   const unsigned long long spt = (unsigned long long)g->tiles_w * g->tiles_h * p.B;
   if (spt == 0 || spt * spt * ((p.Cout + WBN - 1) / WBN) >= (1ull << 32)) return false;    // (keeps the multiply-high exact)
-  g->sp_magic = (unsigned)(((1ull << 32) + spt - 1) / spt);
+  g->sp_magic = spt == 1 ? 0u : (unsigned)(((1ull << 32) + spt - 1) / spt);
   return true;
 }
 int wino_stats_slices(const WinoGeom& g) { return g.tiles_h * g.tiles_w; }

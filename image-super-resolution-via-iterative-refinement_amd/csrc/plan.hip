@@ -712,6 +712,12 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         }
         if (o.tile_cfg == 11 || o.tile_cfg == 12) {
           if (!P->derived_ptr) { set_error("the plan's derived (Winograd) weights are not bound: call sr3_plan_bind_derived + sr3_plan_prepare_derived"); return SR3_E_BADARG; }
+          // stale filters must fail loudly, not compute with the previous weights: the buffer has to have been prepared from
+          // THIS arena, under the current options, and not invalidated since (sr3_plan_invalidate_derived after an optimizer step)
+          if (P->derived_from != params || P->derived_opts != P->gemm1x1) {
+            set_error("the plan's derived (Winograd) weights are stale or were prepared from another arena: call sr3_plan_prepare_derived");
+            return SR3_E_BADARG;
+          }
           c.wino_u = P->derived_ptr + o.wino_off;
         }
         if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
@@ -981,6 +987,12 @@ int sr3_plan_bind_derived(sr3_plan* plan, void* buffer, size_t bytes) {
   }
   plan->derived_ptr = static_cast<float*>(buffer);
   plan->derived_bound_bytes = buffer ? bytes : 0;
+  plan->derived_from = nullptr;               // a freshly bound buffer holds nothing yet
+  return SR3_OK;
+}
+int sr3_plan_invalidate_derived(sr3_plan* plan) {
+  if (!plan) { set_error("null plan"); return SR3_E_BADARG; }
+  plan->derived_from = nullptr;
   return SR3_OK;
 }
 int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) {
@@ -993,6 +1005,8 @@ int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) 
         : wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
+  plan->derived_from = params;
+  plan->derived_opts = plan->gemm1x1;
   return SR3_OK;
 }
 

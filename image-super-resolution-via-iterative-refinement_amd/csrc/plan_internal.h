@@ -111,6 +111,8 @@ struct sr3_plan {
   size_t derived_floats = 0;
   float* derived_ptr = nullptr;
   size_t derived_bound_bytes = 0;
+  const float* derived_from = nullptr;   // the arena sr3_plan_prepare_derived last ran on (null: never / invalidated)
+  int derived_opts = 0;                  // ... and the option state it ran under (the 1x1 entries are skipped when gemm1x1 is off)
   int loss_l2 = 0;           // training loss: 0 = L1 (sum), 1 = L2 (sum)  (set_loss, diffusion.py:84-90)
   // compiled forward
   int built_batch = -1;

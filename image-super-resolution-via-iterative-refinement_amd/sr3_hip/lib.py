@@ -68,6 +68,7 @@ SIGNATURES = {
     'sr3_plan_derived_bytes': (_Z, [_P]),
     'sr3_plan_bind_derived': (_I, [_P, _P, _Z]),
     'sr3_plan_prepare_derived': (_I, [_P, _P, _P]),
+    'sr3_plan_invalidate_derived': (_I, [_P]),
     'sr3_unet_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     'sr3_unet_forward_profile': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P, _I, _P, _P, _P, _P]),
     'sr3_p_sample_step': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

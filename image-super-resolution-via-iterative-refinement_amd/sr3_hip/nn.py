@@ -95,6 +95,8 @@ class EngineUNet(nn.Module):
         """Engine-side writes to the arena through raw pointers (fused Adam) are invisible to torch's version counter:
         the writer calls this."""
         self._weights_epoch += 1
+        # the library refuses to run on filters it was told are stale (include/sr3_mi355x.h); ensure_derived re-prepares
+        L.check(self.plan.lib.sr3_plan_invalidate_derived(self.plan.handle))
 
     def ensure_derived(self):
         """(Re)build the Winograd filters if the parameters moved or changed since the last build.  Views handed out by

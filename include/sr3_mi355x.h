@@ -113,10 +113,17 @@ int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_
  * "winograd", default 1), which reads the transformed filters U = G g G^T from a caller-owned device buffer of
  * sr3_plan_derived_bytes bytes (16/9 of the 3x3 weights).  Bind it once (the pointer is kept, and baked into captured
  * graphs), and re-run sr3_plan_prepare_derived on the stream whenever the parameter arena changed (checkpoint load,
- * optimizer step): ~55 small launches.  sr3_unet_forward fails with SR3_E_BADARG when a plan needs them and none is bound. */
+ * optimizer step): ~55 small launches.
+ * STALE FILTERS FAIL LOUDLY: sr3_unet_forward / sr3_train_step return SR3_E_BADARG when the plan needs the filters and
+ * (a) none is bound, (b) the buffer was never prepared, (c) it was prepared from a different `params` pointer than the
+ * call's, (d) the plan options that decide its content changed since, or (e) sr3_plan_invalidate_derived was called
+ * after the last prepare.  The library cannot see writes to the arena (sr3_adam_step takes no plan): a caller that
+ * updates parameters in place calls sr3_plan_invalidate_derived right after the update and prepares again before the
+ * next forward. */
 size_t sr3_plan_derived_bytes(const sr3_plan* plan);
 int sr3_plan_bind_derived(sr3_plan* plan, void* buffer, size_t bytes);
 int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream);
+int sr3_plan_invalidate_derived(sr3_plan* plan);
 size_t sr3_workspace_bytes(sr3_plan* plan, int batch);
 
 /* UNet.forward (model/sr3_modules/unet.py:235-259, model/ddpm_modules/unet.py:220-243).

@@ -159,3 +159,42 @@ def test_engine_refuses_cpu():
     m, g, sd = build('sr3_tiny')
     with pytest.raises(L.Sr3Error):
         m.netG.denoise_fn(torch.zeros(1, 6, 16, 16), torch.zeros(1, 1))
+
+
+def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
+    """The Winograd / 1x1-GEMM filters live in a derived buffer.  (1) The C ABI refuses a forward on filters it was told are
+    stale (sr3_plan_invalidate_derived: what the fused Adam step's caller does) or that were prepared from another arena,
+    instead of silently computing with the previous weights.  (2) Toggling a plan option that changes the buffer's content
+    (gemm1x1) AFTER a forward rebuilds it: the output still matches the golden eps (the cache key of
+    EngineUNet.ensure_derived includes the plan generation)."""
+    import ctypes as C
+    from sr3_hip import lib as L, engine as E
+    m, g, sd = build('sr3_seam')
+    un = m.netG.denoise_fn
+    d = G.dev()
+    x = torch.from_numpy(g['unet/x']).to(d)
+    t = torch.from_numpy(g['unet/time']).to(d)
+    ref = torch.from_numpy(g['unet/eps'])
+    G.assert_close(un(x, t).cpu(), ref, what='before')
+    assert any(o['tile_cfg'] == 11 for o in un.plan.op_list(x.shape[0])), 'the plan has no Winograd op: nothing derived to test'
+    # (1) raw C-ABI call after an invalidation: loud failure; after prepare: fine again
+    lib = un.plan.lib
+    L.check(lib.sr3_plan_invalidate_derived(un.plan.handle))
+    with pytest.raises(L.Sr3Error, match='stale'):
+        E.unet_forward(un.plan, un.arena.data, un.freq, un._ws, x, noise_level=t)
+    other = un.arena.data.clone()                     # same content, another pointer: prepared-from check
+    L.check(lib.sr3_plan_prepare_derived(un.plan.handle, L.ptr(other), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    with pytest.raises(L.Sr3Error, match='another arena'):
+        E.unet_forward(un.plan, un.arena.data, un.freq, un._ws, x, noise_level=t)
+    un._derived_key = None                            # the module path re-prepares from its own arena
+    G.assert_close(un(x, t).cpu(), ref, what='after re-prepare')
+    # the optimizer-step notification goes through the same door
+    un.weights_changed()
+    with pytest.raises(L.Sr3Error, match='stale'):
+        E.unet_forward(un.plan, un.arena.data, un.freq, un._ws, x, noise_level=t)
+    G.assert_close(un(x, t).cpu(), ref, what='after weights_changed')
+    # (2) option toggle after a forward
+    un.plan.set_option('gemm1x1', 1)
+    G.assert_close(un(x, t).cpu(), ref, what='gemm1x1 on')
+    un.plan.set_option('gemm1x1', 0)
+    G.assert_close(un(x, t).cpu(), ref, what='gemm1x1 off again')
