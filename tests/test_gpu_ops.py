@@ -189,6 +189,56 @@ WINO_CASES = [
 ]
 
 
+STRESS_CASES = [
+    # name, B, C0, C1, H, W, Cout, act, scale of the GroupNorm (scale, shift) pairs
+    ('stress_128_64to64', 2, 64, 0, 128, 128, 64, 2, 30.0),
+    ('stress_32_concat768to256', 1, 512, 256, 32, 32, 256, 2, 30.0),
+    ('stress_16_512to512_affine_only', 2, 512, 0, 16, 16, 512, 1, 300.0),
+]
+
+
+@pytest.mark.parametrize('ksplit', [0, 1])
+@pytest.mark.parametrize('case', STRESS_CASES, ids=[c[0] for c in STRESS_CASES])
+def test_winograd_conv_stress_absolute_bound(case, ksplit):
+    """The Winograd kernel on data built to hurt it -- activations up to ~1e3 after the GroupNorm affine (heavy-tailed, with
+    sign flips between neighbouring pixels, so the input transform's differences cancel), filters with a few output and
+    input channels 30x larger than the rest -- against an ABSOLUTE float64 criterion, not the direct kernel's error:
+    every output element must lie within 4 * gamma_K * conv(|a|, |w|) of the float64 result, K = 9 Cin multiply-adds,
+    gamma_K = K u / (1 - K u), u = 2^-24: four times the classic worst-case bound of a K-term fp32 dot product.  (The
+    F(2x2,3x3) transforms add O(1) roundings per term with coefficients 0, +-1, +-1/2; measured ratios are ~1e-2 of it.)"""
+    import torch.nn.functional as F
+    name, B, C0, C1, H, W, Cout, act, amp = case
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x = x * torch.exp(1.5 * torch.randn(B, Cin, H, W, generator=g))           # log-normal magnitudes: heavy tails
+    checker = ((torch.arange(H)[:, None] + torch.arange(W)[None, :]) % 2 * 2 - 1).float()
+    x[:, ::7] = x[:, ::7].abs() * checker                                     # pixel-to-pixel sign flips on some channels
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    w[::5] *= 30.0                                                            # a few loud output channels
+    w[:, ::11] *= 30.0                                                        # ... and loud input channels
+    ss = torch.stack([torch.randn(B, Cin, generator=g) * amp, torch.randn(B, Cin, generator=g) * amp], dim=2).contiguous()
+    bias = torch.randn(Cout, generator=g)
+    src0, src1 = (x[:, :C0].contiguous(), x[:, C0:].contiguous()) if C1 else (x, None)
+    kw = dict(ups=0, stride=1, act=act, ss=ss, bias=bias)
+    got, _ = G.conv_call(src0, src1, w, tile_cfg=11, ksplit=ksplit, **kw)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    a = x.double() * ss[:, :, 0].double()[:, :, None, None] + ss[:, :, 1].double()[:, :, None, None]
+    if act == 2:
+        a = a * torch.sigmoid(a)
+    mag = F.conv2d(a.abs(), w.double().abs(), None, padding=1) + bias.double().abs()[None, :, None, None]
+    K = 9 * Cin
+    u = 2.0 ** -24
+    gamma = K * u / (1 - K * u)
+    err = (got.double() - ref).abs()
+    ratio = (err / (4 * gamma * mag + 1e-300)).max().item()
+    print('%s ks%d: |a|max %.3g, |ref|max %.3g, max err %.3g, max err / (4 gamma_K conv(|a|,|w|)) = %.3g'
+          % (name, ksplit, a.abs().max().item(), ref.abs().max().item(), err.max().item(), ratio))
+    assert torch.isfinite(got).all()
+    assert a.abs().max().item() > 500.0                                      # the case really is a stress case
+    assert ratio <= 1.0, ratio
+
+
 @pytest.mark.parametrize('ksplit', [0, 1, 3])
 @pytest.mark.parametrize('case', WINO_CASES, ids=[c[0] for c in WINO_CASES])
 def test_winograd_conv_error_is_fp32_class(case, ksplit):
