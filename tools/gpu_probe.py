@@ -54,7 +54,20 @@ def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2
         ('k1_16_1024_512', 512, 512, 16, 512, 1, 1, 0, 0),
         ('k1_128_192_64', 128, 64, 128, 64, 1, 1, 0, 0),
     ]
-    if only:
+    if only and 'net1x1' in only:
+        # every 1x1 / stride-2 conv shape of the C2 forward (tools/op_table.py): (name, C0, C1, H, Cout, k, stride, ups, act)
+        shapes = [('k1_64_64_128', 64, 0, 64, 128, 1, 1, 0, 0), ('k1_32_128_256', 128, 0, 32, 256, 1, 1, 0, 0),
+                  ('k1_16_256_512', 256, 0, 16, 512, 1, 1, 0, 0), ('k1_16_512_1536', 512, 0, 16, 1536, 1, 1, 0, 1),
+                  ('k1_16_512_512', 512, 0, 16, 512, 1, 1, 0, 0), ('k1_8_512_1536', 512, 0, 8, 1536, 1, 1, 0, 1),
+                  ('k1_8_512_512', 512, 0, 8, 512, 1, 1, 0, 0), ('k1_8_1024_512', 512, 512, 8, 512, 1, 1, 0, 0),
+                  ('k1_16_1024_512', 512, 512, 16, 512, 1, 1, 0, 0), ('k1_16_768_512', 512, 256, 16, 512, 1, 1, 0, 0),
+                  ('k1_32_768_256', 512, 256, 32, 256, 1, 1, 0, 0), ('k1_32_512_256', 256, 256, 32, 256, 1, 1, 0, 0),
+                  ('k1_32_384_256', 256, 128, 32, 256, 1, 1, 0, 0), ('k1_64_384_128', 256, 128, 64, 128, 1, 1, 0, 0),
+                  ('k1_64_256_128', 128, 128, 64, 128, 1, 1, 0, 0), ('k1_64_192_128', 128, 64, 64, 128, 1, 1, 0, 0),
+                  ('k1_128_192_64', 128, 64, 128, 64, 1, 1, 0, 0), ('k1_128_128_64', 64, 64, 128, 64, 1, 1, 0, 0),
+                  ('s2_128_64', 64, 0, 128, 64, 3, 2, 0, 0), ('s2_64_128', 128, 0, 64, 128, 3, 2, 0, 0),
+                  ('s2_32_256', 256, 0, 32, 256, 3, 2, 0, 0), ('s2_16_512', 512, 0, 16, 512, 3, 2, 0, 0)]
+    elif only:
         shapes = [s_ for s_ in shapes if s_[0] in only]
     if quick:
         shapes = shapes[:2] + shapes[7:8] + shapes[9:10] + shapes[11:12]
@@ -93,6 +106,7 @@ def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2
                         L.check(lib.sr3_conv_f32(L.ptr(s0), C0, L.ptr(s1), C1, B, H, H, ups, stride, k, Cout, L.ptr(w),
                                                  L.ptr(bias), L.ptr(ss), act, None, 0, None, 0, None, 0, L.ptr(out),
                                                  None, cfg, ks, L.ptr(scratch), nb, st))
+                    print('run', name, cfg, ks, nb, flush=True)
                     try:
                         ms = time_fn(run)
                     except L.Sr3Error as e:
