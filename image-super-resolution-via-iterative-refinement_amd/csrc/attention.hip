@@ -11,6 +11,8 @@
 // LDS write) and double-buffered in LDS when the strip leaves room (NSTAGE = 2).  When the grid
 // would leave CUs idle, the channel panels of phase 3 are split over gridDim.z workgroups (each
 // recomputes the cheap score strip).
+#include <stdlib.h>
+
 #include "sr3_common.h"
 
 namespace sr3 {
@@ -196,9 +198,201 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same computation with NO operand staging -- every MFMA operand except the probabilities comes straight from
+// global memory in fragment form, because on this part nothing overlaps the fp32 MFMA (profiles/r03_mfma_overlap.txt), so
+// the cheapest operand is the one that costs the fewest instructions:
+//   phase 1  S = Q K^T / sqrt(C): a lane's A / B operand for 4 consecutive k-steps is 16 contiguous bytes of ITS query /
+//            key row (qkv is channel-contiguous), i.e. one global_load_dwordx4; a key block belongs to exactly one wave, so
+//            LDS would only add a write and a read per fragment.  KP key blocks per wave share the Q fragment.
+//   phase 2  exact row softmax in the LDS strip (as above).
+//   phase 3  O = P V: A = P from the strip (one ds_read_b128 per 4 k-steps); the wave's TN 32-channel MFMA tiles take the
+//            INTERLEAVED channels c0 + TN n + t (tile t, column n), so one TN-float load per lane and k-step feeds all TN
+//            tiles and the accumulators of a row come out as TN consecutive channels (vector stores).
+// No barrier inside either loop; D = 4 operand groups are in flight per wave (the grid is one workgroup per CU, i.e. one wave
+// per SIMD: the L2 latency has to be covered inside the wave).  Workgroups are numbered so that all workgroups of an image
+// land on ONE XCD (round-robin dispatch: linear id mod 8): its K / V are then fetched into one L2 instead of eight.
+// The k order of both contractions is the one of k_attention (bitwise equal results).
+// Shapes: N % 32 == 0, N <= 1024, C % 128 == 0, (C / zsplit) % (128 TN) == 0; the rest stays on k_attention.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TN> struct AtVec;
+template <> struct AtVec<1> { typedef float type; };
+template <> struct AtVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct AtVec<4> { typedef f32x4 type; };
+template <int TN> __device__ __forceinline__ float at_elem(const typename AtVec<TN>::type& v, int t) { return v[t]; }
+template <> __device__ __forceinline__ float at_elem<1>(const float& v, int) { return v; }
+
+template <int KP, int TN>
+__global__ __launch_bounds__(256) void k_attention_v2(const float* __restrict__ qkv, int B, int N, int C, int zsplit,
+                                                       float* __restrict__ out) {
+  extern __shared__ f32x4 smem_v[];
+  float* S = reinterpret_cast<float*>(smem_v);              // [32][N + 4]
+  const int LDS_S = N + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (query block, channel split, image) of this workgroup; B % 8 == 0: image = xcd + 8 * (...), xcd = linear id mod 8
+  const int qblocks = N >> 5, per_img = qblocks * zsplit;
+  int b, r;
+  if ((B & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    b = xcd + 8 * (j / per_img);
+    r = j % per_img;
+  } else {
+    b = blockIdx.x / per_img;
+    r = blockIdx.x % per_img;
+  }
+  const int m0 = (r % qblocks) * 32, zi = r / qblocks;
+  const int rowstride = 3 * C;
+  const float* base = qkv + (size_t)b * N * rowstride;
+  const int ln = lane & 31, kh = (lane >> 5) * 4;
+  const float sqrt_c = sqrtf((float)C);
+  constexpr int D = 4;                                      // operand groups in flight
+
+  // ---------------- phase 1 ----------------
+  {
+    const int KB = N >> 5, G = C >> 3;                      // G % D == 0 (C % 32 == 0: host)
+    const float* qrow = base + (size_t)(m0 + ln) * rowstride + kh;
+    for (int kb0 = wave * KP; kb0 < KB; kb0 += 4 * KP) {
+      const float* krow[KP];
+#pragma unroll
+      for (int p = 0; p < KP; ++p) krow[p] = base + (size_t)(min(kb0 + p, KB - 1) * 32 + ln) * rowstride + C + kh;
+      f32x16 acc[KP];
+#pragma unroll
+      for (int p = 0; p < KP; ++p)
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) acc[p][r_] = 0.f;
+      f32x4 a[D], k4[D][KP];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        a[d] = *reinterpret_cast<const f32x4*>(qrow + d * 8);
+#pragma unroll
+        for (int p = 0; p < KP; ++p) k4[d][p] = *reinterpret_cast<const f32x4*>(krow[p] + d * 8);
+      }
+      for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < KP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[d][q], k4[d][p][q], acc[p], 0, 0, 0);
+          const int gn = min(g0 + d + D, G - 1) * 8;          // (the tail re-fetches the last group: the loads stay unconditional)
+          a[d] = *reinterpret_cast<const f32x4*>(qrow + gn);
+#pragma unroll
+          for (int p = 0; p < KP; ++p) k4[d][p] = *reinterpret_cast<const f32x4*>(krow[p] + gn);
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < KP; ++p) {
+        if (kb0 + p < KB) {
+          const int key = (kb0 + p) * 32 + ln;
+#pragma unroll
+          for (int r_ = 0; r_ < 16; ++r_) S[((r_ & 3) + 8 * (r_ >> 2) + kh) * LDS_S + key] = acc[p][r_] / sqrt_c;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: row softmax ----------------
+  {
+    const int row = tid >> 3, sub = tid & 7;
+    float* sr = S + row * LDS_S;
+    float mx = -INFINITY;
+    for (int k = sub; k < N; k += 8) mx = fmaxf(mx, sr[k]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    float sum = 0.f;
+    for (int k = sub; k < N; k += 8) { const float e = expf(sr[k] - mx); sr[k] = e; sum += e; }
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    sum += __shfl_xor(sum, 4);
+    for (int k = sub; k < N; k += 8) sr[k] = sr[k] / sum;
+  }
+  __syncthreads();
+
+  // ---------------- phase 3 ----------------
+  {
+    typedef typename AtVec<TN>::type vec_t;
+    const int Cz = C / zsplit;
+    const int cz0 = zi * Cz;
+    const int G = N >> 3;                                     // G % D == 0 (N % 32 == 0)
+    for (int cw = wave * 32 * TN; cw < Cz; cw += 4 * 32 * TN) {
+      const int c0 = cz0 + cw;
+      const float* vcol = base + 2 * C + c0 + TN * ln + (size_t)kh * rowstride;       // key kh, this lane's TN channels
+      const float* prow = S + ln * LDS_S + kh;
+      f32x16 acc[TN];
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) acc[t][r_] = 0.f;
+      vec_t vb[D][4];
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + (size_t)(d * 8 + q) * rowstride);
+      for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(prow + (g0 + d) * 8);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], at_elem<TN>(vb[d][q], t), acc[t], 0, 0, 0);
+          const size_t kn = (size_t)(min(g0 + d + D, G - 1) * 8) * rowstride;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + kn + (size_t)q * rowstride);
+        }
+      }
+      float* orow = out + ((size_t)b * N + m0) * C + c0 + TN * ln;
+#pragma unroll
+      for (int r_ = 0; r_ < 16; ++r_) {
+        const int row = (r_ & 3) + 8 * (r_ >> 2) + kh;
+        vec_t o;
+        if constexpr (TN == 1) o = acc[0][r_];
+        else {
+#pragma unroll
+          for (int t = 0; t < TN; ++t) o[t] = acc[t][r_];
+        }
+        *reinterpret_cast<vec_t*>(orow + (size_t)row * C) = o;
+      }
+    }
+  }
+}
+
+namespace {
+template <int KP, int TN>
+int launch_attention_v2(const float* qkv, int B, int N, int C, int zsplit, float* out, hipStream_t st) {
+  static std::atomic<uint64_t> done{0};
+  const int smem = 32 * (N + 4) * (int)sizeof(float);
+  auto kern = k_attention_v2<KP, TN>;
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024, done)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((N / 32) * B * zsplit)), dim3(256), smem, st, qkv, B, N, C, zsplit, out);
+  SR3_LAUNCH_CHECK("k_attention_v2");
+  return SR3_OK;
+}
+}  // namespace
+
 int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st) {
   if (C & 3) { set_error("attention: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   if ((double)B * N * 3.0 * C >= 2147483647.0) { set_error("attention: qkv exceeds 2^31 elements"); return SR3_E_UNSUPPORTED; }
+  // the staging-free kernel wherever the shape allows it (SR3_ATTN_V1=1, read once: A/B knob for the profiles)
+  static const bool force_v1 = [] { const char* e = getenv("SR3_ATTN_V1"); return e && e[0] == '1'; }();
+  if (!force_v1 && (N & 31) == 0 && N <= 1024 && (C % 128) == 0) {
+    const int qblocks = N / 32;
+    int zsplit = 1;                                       // channel split of phase 3 (each split recomputes the score strip)
+    while ((long)qblocks * B * zsplit < 256 && (C / (zsplit * 2)) % 128 == 0 && zsplit < 4) zsplit *= 2;
+    const int Cz = C / zsplit;
+    const int tn = (Cz % 512 == 0) ? 4 : ((Cz % 256 == 0) ? 2 : 1);
+    const bool pairs = N / 32 >= 8;                       // two key blocks per wave and round share the Q fragment
+    if (pairs) {
+      if (tn == 4) return launch_attention_v2<2, 4>(qkv, B, N, C, zsplit, out, st);
+      if (tn == 2) return launch_attention_v2<2, 2>(qkv, B, N, C, zsplit, out, st);
+      return launch_attention_v2<2, 1>(qkv, B, N, C, zsplit, out, st);
+    }
+    if (tn == 4) return launch_attention_v2<1, 4>(qkv, B, N, C, zsplit, out, st);
+    if (tn == 2) return launch_attention_v2<1, 2>(qkv, B, N, C, zsplit, out, st);
+    return launch_attention_v2<1, 1>(qkv, B, N, C, zsplit, out, st);
+  }
   const int Npad = (N + 31) & ~31;
   const size_t strip = (size_t)32 * (Npad + 4);
   int nstage = 2;

@@ -559,6 +559,10 @@ static void walk_forward(sr3_plan* P, Builder& bld, int cond_channels) {
       Op o; o.kind = OP_CONV_IN;
       o.e = bld.T[cur].off; o.p0 = L.w; o.p1 = L.b;
       o.i0 = d.in_channel - cond_channels; o.i1 = cond_channels; o.i2 = L.cout; o.i3 = S;
+      if (const int slices = P->fuse_stats ? conv_in_stat_slices(d.in_channel, S, S, L.cout) : 0) {
+        bld.stat_slot(cur, slices);          // the MFMA form writes the GroupNorm partials of its output itself
+        o.has_ostat = true; o.f = bld.T[cur].stat_off;
+      }
       ops.push_back(o);
       if (bld.train) { Rec r; r.kind = R_CONV_IN; r.out = cur; r.w = L.w; r.bias = L.b; P->recs.push_back(r); }
       bld.flops += 2.0 * B * S * S * (double)L.cout * L.cin * 9;
@@ -675,7 +679,8 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         const float* b = cond_channels > 0 ? x : nullptr;
         const int Cb = cond_channels > 0 ? o.i0 : 0;
         rc = conv_in_nchw(a, Ca, b, Cb, B, o.i3, o.i3, params + o.p0, params + o.p1, o.i2,
-                          reinterpret_cast<float*>(ws + o.e), nullptr, st);
+                          reinterpret_cast<float*>(ws + o.e),
+                          o.has_ostat ? reinterpret_cast<double*>(ws + R.stats_off + o.f) : nullptr, st);
         break;
       }
       case OP_STATS:
@@ -935,6 +940,9 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
     out->fused_res_conv_cin = o.has_x2 ? c.x2_C0 + c.x2_C1 : 0;
     out->fused_output_stats = o.has_ostat ? 1 : 0;
     out->flops = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)out->cin * c.ksize * c.ksize + out->fused_res_conv_cin);
+  } else if (o.kind == OP_CONV_IN) {
+    out->ksize = 3; out->stride = 1; out->cin = o.i0 + o.i1; out->cout = o.i2; out->h_out = out->w_out = o.i3;
+    out->fused_output_stats = o.has_ostat ? 1 : 0;
   } else if (o.kind == OP_ATTN) {
     out->h_out = o.i0; out->cin = out->cout = o.i1;          // tokens, channels
     out->flops = 4.0 * batch * (double)o.i0 * (double)o.i0 * o.i1;

@@ -213,9 +213,136 @@ __global__ __launch_bounds__(256) void k_conv_in_nchw(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same conv on the fp32 MFMA (round 3; the VALU form above stays for shapes this one does not take).  GEMM view:
+// out[m][n] = sum_k x[m][k] w[n][k], k = tap * CIN + c (the OHWI filter row as it lies in memory), two k per
+// v_mfma_f32_32x32x2_f32.  A wave owns 32 consecutive pixels of one image row: lane (pixel l & 31, k-half l >> 5) reads its A
+// value straight from the NCHW plane (32 lanes = 128 contiguous bytes), no LDS anywhere; the whole filter bank (KS x NB
+// registers) is loaded once per wave and reused for `bpw` pixel blocks.  Epilogue: + bias, NHWC stores (a register's 32
+// lanes = 32 consecutive channels of a pixel), and the per-(image, slice, channel) GroupNorm partial sums in double --
+// the stand-alone statistics pass over this 67 MB tensor goes away (slice = the bpw blocks of one wave).
+// Needs W % 32 == 0, Cout = 32 NB, CIN in {3, 6}.
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int NB>
+__global__ __launch_bounds__(256) void k_conv_in_mfma(const float* __restrict__ a, int Ca, const float* __restrict__ bsrc,
+                                                       int Cb, int B, int H, int W, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       double* __restrict__ ostat, int bpw, int T) {
+  constexpr int K = 9 * CIN, KS = (K + 1) / 2, Cout = 32 * NB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ln = lane & 31, h = lane >> 5;
+  const int HW = H * W, bpi = HW >> 5;                       // 32-pixel blocks per image
+  const int task = blockIdx.x * 4 + wave;
+  if (task >= B * (bpi / bpw)) return;                       // (no barrier in this kernel)
+  const int blk0 = task * bpw;
+  const int b = blk0 / bpi;
+  const int slice = (blk0 - b * bpi) / bpw;
+
+  float bw[KS][NB], bn[NB];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int k = 2 * s + h;
+      bw[s][nb] = k < K ? w[(size_t)(nb * 32 + ln) * K + k] : 0.f;
+    }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bn[nb] = bias ? bias[nb * 32 + ln] : 0.f;
+
+  const float* plane[CIN];                                   // channel planes of image b: the virtual concat [a | bsrc]
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+    plane[c] = c < Ca ? a + ((size_t)b * Ca + c) * HW : bsrc + ((size_t)b * Cb + (c - Ca)) * HW;
+
+  auto load_block = [&](int blk, float (&av)[KS]) {
+    const int p0 = (blk - b * bpi) * 32;                     // first pixel of the block inside the image (one image row)
+    const int oh = p0 / W, ow = p0 - oh * W + ln;
+    const int pixoff = oh * W + ow;
+    const bool up = oh > 0, down = oh < H - 1, left = ow > 0, right = ow < W - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      constexpr int dummy = 0; (void)dummy;
+      const int k0 = 2 * s, k1 = 2 * s + 1;                  // compile-time after unrolling
+      const int t0 = k0 / CIN, c0 = k0 - t0 * CIN, t1 = k1 / CIN, c1 = (k1 < K) ? k1 - t1 * CIN : 0;
+      const int dy0 = t0 / 3 - 1, dx0 = t0 % 3 - 1, dy1 = (k1 < K) ? t1 / 3 - 1 : 0, dx1 = (k1 < K) ? t1 % 3 - 1 : 0;
+      const bool v0 = (dy0 < 0 ? up : (dy0 > 0 ? down : true)) && (dx0 < 0 ? left : (dx0 > 0 ? right : true));
+      const bool v1 = (k1 < K) && (dy1 < 0 ? up : (dy1 > 0 ? down : true)) && (dx1 < 0 ? left : (dx1 > 0 ? right : true));
+      const bool valid = h ? v1 : v0;
+      const float* pl = h ? plane[c1] : plane[c0];
+      const int d = h ? dy1 * W + dx1 : dy0 * W + dx0;
+      const float v = pl[pixoff + (valid ? d : 0)];          // unconditional load (the centre pixel when the tap is padding)
+      av[s] = valid ? v : 0.f;
+    }
+  };
+
+  double s1[NB], s2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) { s1[nb] = 0.0; s2[nb] = 0.0; }
+  float av[KS], an[KS];
+  load_block(blk0, av);
+  for (int i = 0; i < bpw; ++i) {
+    load_block(blk0 + min(i + 1, bpw - 1), an);              // (the last block re-fetches itself)
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s][nb], acc[nb], 0, 0, 0);
+    const size_t m0 = (size_t)(blk0 + i) * 32;               // NHWC row of the block's first pixel
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[nb][r] + bn[nb];
+        out[(m0 + row) * Cout + nb * 32 + ln] = v;
+        if (ostat) { const double dv = (double)v; s1[nb] += dv; s2[nb] += dv * dv; }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) av[s] = an[s];
+  }
+  if (ostat) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const double t1 = s1[nb] + __shfl_xor(s1[nb], 32), t2 = s2[nb] + __shfl_xor(s2[nb], 32);
+      if (h == 0) {
+        double* o = ostat + (((size_t)b * T + slice) * Cout + nb * 32 + ln) * 2;
+        o[0] = t1; o[1] = t2;
+      }
+    }
+  }
+}
+
+// 32-pixel blocks per wave of the MFMA form (0: the shape stays on the VALU kernel); also the statistics slices per image
+static int conv_in_bpw(int Cin, int H, int W, int Cout) {
+  if ((Cin != 3 && Cin != 6) || (W & 31) || (Cout & 31) || Cout > 128 || Cout < 32) return 0;
+  const int bpi = H * W / 32;
+  return (bpi % 4 == 0) ? 4 : 1;
+}
+int conv_in_stat_slices(int Cin, int H, int W, int Cout) {
+  const int bpw = conv_in_bpw(Cin, H, W, Cout);
+  return bpw ? H * W / 32 / bpw : 0;
+}
+
 int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
                  const float* bias, int Cout, float* out, double* ostat, hipStream_t st) {
-  (void)ostat;
+  if (const int bpw = conv_in_bpw(Ca + Cb, H, W, Cout)) {
+    const int T = H * W / 32 / bpw;
+    const long tasks = (long)B * T;
+    const dim3 grid((unsigned)((tasks + 3) / 4));
+#define SR3_CI(CIN, NB) hipLaunchKernelGGL((k_conv_in_mfma<CIN, NB>), grid, dim3(256), 0, st, a, Ca, b, Cb, B, H, W, w, bias, out, ostat, bpw, T)
+    const int nb = Cout / 32;
+    if (Ca + Cb == 6) { if (nb == 1) SR3_CI(6, 1); else if (nb == 2) SR3_CI(6, 2); else if (nb == 3) SR3_CI(6, 3); else SR3_CI(6, 4); }
+    else { if (nb == 1) SR3_CI(3, 1); else if (nb == 2) SR3_CI(3, 2); else if (nb == 3) SR3_CI(3, 3); else SR3_CI(3, 4); }
+#undef SR3_CI
+    SR3_LAUNCH_CHECK("k_conv_in_mfma");
+    return SR3_OK;
+  }
+  if (ostat) { set_error("conv_in: fused output statistics need the MFMA form (W %% 32 == 0, Cout %% 32 == 0, 3 or 6 input channels)"); return SR3_E_UNSUPPORTED; }
   if (Cout & 3) { set_error("conv_in: Cout %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   const int CoutP = (Cout + 63) & ~63;
   const size_t smem = (size_t)9 * (Ca + Cb) * CoutP * sizeof(float);
@@ -235,14 +362,14 @@ int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, i
 // accumulates its pixel's Cout outputs from LDS.  Writes NCHW (the public layout of eps).
 // ---------------------------------------------------------------------------------------------
 constexpr int OT_H = 8, OT_W = 32, OT_CK = 16, OT_LD = 20;
+// COUT: output channels (1..4); FULL: C is a multiple of the 16-channel chunk (no per-quad bound checks)
+template <int COUT, bool FULL>
 __global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__ x, const float* __restrict__ ss,
                                                         int B, int H, int W, int C, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int Cout,
                                                         float* __restrict__ out) {
   __shared__ f32x4 tile_v[(OT_H + 2) * (OT_W + 2) * OT_LD / 4];
-  __shared__ f32x4 wl_v[4 * 9 * OT_CK / 4];
   float* tile = reinterpret_cast<float*>(tile_v);
-  float* wl = reinterpret_cast<float*>(wl_v);              // [co][tap][16]
   const int tid = threadIdx.x;
   const int tx = tid & 31, ty = tid >> 5;
   const int tiles_w = (W + OT_W - 1) / OT_W, tiles_h = (H + OT_H - 1) / OT_H;
@@ -269,32 +396,33 @@ __global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__
       }
       *reinterpret_cast<f32x4*>(tile + pix * OT_LD + q * 4) = v;
     }
-    for (int i = tid; i < 4 * 9 * OT_CK; i += 256) {
-      const int co = i / (9 * OT_CK), r = i - co * 9 * OT_CK;
-      const int tap = r / OT_CK, c = c0 + (r - tap * OT_CK);
-      wl[i] = (co < Cout && c < C) ? w[((size_t)co * 9 + tap) * C + c] : 0.f;
-    }
     __syncthreads();
+    // The filter taps are the same for every lane: they are read through workgroup-uniform addresses, i.e. scalar loads into
+    // SGPRs that feed the FMAs directly (round 3; the LDS copy of the weights cost 4 broadcast ds_read_b128 per tile read and
+    // made the kernel LDS-instruction bound: 62 -> measured in profiles/r03*).  Same FMA order as before: (tap, quad, element).
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const float* tp = tile + ((ty + tap / 3) * (OT_W + 2) + tx + tap % 3) * OT_LD;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tp + q * 4);
+        if (FULL || c0 + q * 4 < C) {                             // uniform
+          const f32x4 v = *reinterpret_cast<const f32x4*>(tp + q * 4);
 #pragma unroll
-        for (int co = 0; co < 4; ++co) {
-          const f32x4 ww = *reinterpret_cast<const f32x4*>(wl + (co * 9 + tap) * OT_CK + q * 4);
-          acc[co] = fmaf(v[0], ww[0], acc[co]);
-          acc[co] = fmaf(v[1], ww[1], acc[co]);
-          acc[co] = fmaf(v[2], ww[2], acc[co]);
-          acc[co] = fmaf(v[3], ww[3], acc[co]);
+          for (int co = 0; co < COUT; ++co) {
+            const float* wr = w + ((size_t)co * 9 + tap) * C + c0 + q * 4;
+            acc[co] = fmaf(v[0], wr[0], acc[co]);
+            acc[co] = fmaf(v[1], wr[1], acc[co]);
+            acc[co] = fmaf(v[2], wr[2], acc[co]);
+            acc[co] = fmaf(v[3], wr[3], acc[co]);
+          }
         }
       }
     }
   }
   const int oh = h0 + ty, ow = w0 + tx;
   if (oh < H && ow < W) {
-    for (int co = 0; co < Cout; ++co)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
       out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + (bias ? bias[co] : 0.f);
   }
 }
@@ -304,7 +432,18 @@ int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, c
   if (Cout > 4 || Cout < 1) { set_error("conv_out: Cout %d > 4 unsupported", Cout); return SR3_E_UNSUPPORTED; }
   if (C & 3) { set_error("conv_out: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   const int tiles = ((W + OT_W - 1) / OT_W) * ((H + OT_H - 1) / OT_H) * B;
-  hipLaunchKernelGGL(k_conv_out_nchw, dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw);
+#define SR3_CO_LAUNCH(N)                                                                                                    \
+  {                                                                                                                          \
+    if (C % OT_CK == 0) hipLaunchKernelGGL((k_conv_out_nchw<N, true>), dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw); \
+    else hipLaunchKernelGGL((k_conv_out_nchw<N, false>), dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw);            \
+  }
+  switch (Cout) {
+    case 1: SR3_CO_LAUNCH(1) break;
+    case 2: SR3_CO_LAUNCH(2) break;
+    case 3: SR3_CO_LAUNCH(3) break;
+    default: SR3_CO_LAUNCH(4) break;
+  }
+#undef SR3_CO_LAUNCH
   SR3_LAUNCH_CHECK("k_conv_out_nchw");
   return SR3_OK;
 }

@@ -177,6 +177,8 @@ int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1
 int halo_stats_slices(const HaloGeom& g);
 // first conv of the UNet: NCHW inputs (virtual concat of a: Ca, b: Cb channels), 3x3 pad 1,
 // weights OHWI [Cout][9][Ca+Cb], output NHWC [B,H,W,Cout]
+// statistics partials per image conv_in_nchw writes into `ostat` for this shape (0: no fused statistics: VALU kernel)
+int conv_in_stat_slices(int Cin, int H, int W, int Cout);
 int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
                  const float* bias, int Cout, float* out, double* ostat, hipStream_t st);
 // final Block: silu(gn(x)) -> conv3x3 C->Cout(<=4), NHWC in, NCHW out

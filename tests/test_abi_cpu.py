@@ -161,7 +161,8 @@ def test_plan_launch_list_no_gpu():
     # default inference plan: every 3x3 stride-1 conv on a map of 16x16 or larger on the Winograd F(2x2,3x3) kernel
     # (tile 11); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
     wops = p.op_list(16)
-    assert len(wops) == p.num_ops(16) == 169
+    assert len(wops) == p.num_ops(16) == 168      # (round 3: the input conv writes its own GroupNorm partials: no statistics pass)
+    assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:      # 8x8 maps keep the direct halo kernel (split-K, so without the fused res_conv segment)
         assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
@@ -172,7 +173,7 @@ def test_plan_launch_list_no_gpu():
     # the direct kernels (plan option winograd = 0; also what the training plan and an explicit tile_cfg use)
     p.set_option('winograd', 0)
     ops = p.op_list(16)
-    assert len(ops) == p.num_ops(16) == 151 + 11
+    assert len(ops) == p.num_ops(16) == 150 + 11
     convs = [o for o in ops if o['kind'] == 50]
     assert sum(1 for o in ops if o['kind'] == 60) == 6 and sum(1 for o in ops if o['kind'] == 40) == 61
     # every 3x3 stride-1 conv runs on the halo-tile kernel; 1x1 and stride-2 convs on the im2col kernel
