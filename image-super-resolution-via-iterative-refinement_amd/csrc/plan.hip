@@ -1114,6 +1114,14 @@ int sr3_p_sample_step(float* x, const float* eps, const float* z, const float* t
   return p_sample_update(x, eps, z, t, step_dev, t_per_sample, step_host, batch, elems_per_image,
                          static_cast<hipStream_t>(stream));
 }
+int sr3_p_sample_step_ex(float* x, const float* eps, const float* z, const float* ta, const float* tb, const float* tc1,
+                         const float* tc2, const float* tsig, const int* step_dev, const int64_t* t_per_sample,
+                         int step_host, int batch, int elems_per_image, int clip_denoised, void* stream) {
+  if (!x || !eps || !ta || !tb || !tc1 || !tc2 || !tsig) { set_error("null argument"); return SR3_E_BADARG; }
+  StepTables t{ta, tb, tc1, tc2, tsig};
+  return p_sample_update(x, eps, z, t, step_dev, t_per_sample, step_host, batch, elems_per_image,
+                         static_cast<hipStream_t>(stream), clip_denoised != 0);
+}
 int sr3_step_decrement(int* step_dev, void* stream) { return step_decrement(step_dev, static_cast<hipStream_t>(stream)); }
 int sr3_q_sample(const float* x0, const float* z, const float* ca, const float* cb, int batch, int elems_per_image,
                  float* out, void* stream) {

@@ -520,6 +520,7 @@ int embed_forward(const EmbedParams& p, hipStream_t st) {
 // reference's elementwise torch ops for the same eps.  t comes from a device counter (graph
 // replay), a per-sample int64 array (DDPM API) or the host.
 // ---------------------------------------------------------------------------------------------
+template <bool CLIP>
 __global__ __launch_bounds__(256) void k_p_sample_update(float* __restrict__ x, const float* __restrict__ eps,
                                                           const float* __restrict__ z, StepTables tb,
                                                           const int* __restrict__ step_dev,
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(256) void k_p_sample_update(float* __restrict__ x, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float x0 = sub_rn(mul_rn(a, xv[k]), mul_rn(bb, ev[k]));
-      x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (CLIP) x0 = fminf(fmaxf(x0, -1.f), 1.f);          // clip_denoised (sr3 diffusion.py:162-163)
       const float mean = add_rn(mul_rn(c1, x0), mul_rn(c2, xv[k]));
       xv[k] = add_rn(mean, mul_rn(zv[k], sg));
     }
@@ -546,13 +547,15 @@ __global__ __launch_bounds__(256) void k_p_sample_update(float* __restrict__ x, 
 }
 
 int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
-                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st) {
+                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st, bool clip) {
   if (per_image & 3) { set_error("p_sample_update: per-image size %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   const size_t total4 = (size_t)B * per_image / 4;
   int blocks = (int)((total4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_p_sample_update, dim3(blocks), dim3(256), 0, st, x, eps, z, tb, step_dev, t_per_sample,
-                     step_host, per_image, total4);
+  if (clip) hipLaunchKernelGGL(k_p_sample_update<true>, dim3(blocks), dim3(256), 0, st, x, eps, z, tb, step_dev, t_per_sample,
+                               step_host, per_image, total4);
+  else hipLaunchKernelGGL(k_p_sample_update<false>, dim3(blocks), dim3(256), 0, st, x, eps, z, tb, step_dev, t_per_sample,
+                          step_host, per_image, total4);
   SR3_LAUNCH_CHECK("k_p_sample_update");
   return SR3_OK;
 }

@@ -206,7 +206,7 @@ int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStre
 // fused reverse-step update (NCHW, elementwise): coef = {a, b, c1, c2, sigma} tables of length T
 struct StepTables { const float* a; const float* b; const float* c1; const float* c2; const float* sigma; };
 int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
-                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st);
+                    const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st, bool clip = true);
 int step_decrement(int* step_dev, hipStream_t st);
 // q_sample (sr3: per-sample gamma; ddpm: a[t], s[t]) -> x_noisy ; l1 loss sum
 int q_sample(const float* x0, const float* z, const float* ca, const float* cb, int B, int per_image,

@@ -17,6 +17,16 @@ class GaussianDiffusion(EngineDiffusion):
         return self._p_sample(x, t, clip_denoised=clip_denoised, repeat_noise=repeat_noise, condition_x=condition_x,
                               noise=noise)
 
+    def q_posterior(self, x_start, x_t, t):
+        """reference :162-172: the DDPM class returns THREE values (mean, variance, clipped log variance)."""
+        mean, logvar = super().q_posterior(x_start, x_t, t)
+        return mean, self._coef('posterior_variance', t, x_t), logvar
+
+    def p_mean_variance(self, x, t, clip_denoised: bool, condition_x=None):
+        """reference :174-189: (model_mean, posterior_variance, posterior_log_variance), per-sample t."""
+        mean, logvar = super().p_mean_variance(x, t, clip_denoised, condition_x=condition_x)
+        return mean, self._coef('posterior_variance', t, x), logvar
+
     def q_sample(self, x_start, t, noise=None):
         """reference :259-267: sqrt(abar_t) * x0 + sqrt(1 - abar_t) * noise."""
         return self._q_sample(x_start, t, noise)

@@ -120,13 +120,14 @@ class EngineDiffusion(nn.Module):
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def _step_update(self, x, eps, z, step_dev=None, t_per_sample=None, step_host=0):
+    def _step_update(self, x, eps, z, step_dev=None, t_per_sample=None, step_host=0, clip_denoised=True):
         lib = L.load()
         per = x[0].numel()
-        L.check(lib.sr3_p_sample_step(L.ptr(x), L.ptr(eps), L.ptr(z), L.ptr(self.sqrt_recip_alphas_cumprod),
-                                      L.ptr(self.sqrt_recipm1_alphas_cumprod), L.ptr(self.posterior_mean_coef1),
-                                      L.ptr(self.posterior_mean_coef2), L.ptr(self._sigma), L.ptr(step_dev),
-                                      L.ptr(t_per_sample), int(step_host), x.shape[0], per, self._stream(x.device)))
+        L.check(lib.sr3_p_sample_step_ex(L.ptr(x), L.ptr(eps), L.ptr(z), L.ptr(self.sqrt_recip_alphas_cumprod),
+                                         L.ptr(self.sqrt_recipm1_alphas_cumprod), L.ptr(self.posterior_mean_coef1),
+                                         L.ptr(self.posterior_mean_coef2), L.ptr(self._sigma), L.ptr(step_dev),
+                                         L.ptr(t_per_sample), int(step_host), x.shape[0], per, 1 if clip_denoised else 0,
+                                         self._stream(x.device)))
 
     def _eps(self, x, t, condition_x):
         """denoise_fn call of p_mean_variance (sr3 :151-160, ddpm :175-182)."""
@@ -139,22 +140,18 @@ class EngineDiffusion(nn.Module):
         return self.denoise_fn(x, tt, cond=condition_x)
 
     def p_mean_variance(self, x, t, clip_denoised: bool, condition_x=None):
-        if not clip_denoised:
-            raise NotImplementedError('clip_denoised=False is never used by the reference callers')
         eps = self._eps(x, t, condition_x)
         mean = x.clone()
         if torch.is_tensor(t):
-            self._step_update(mean, eps, None, t_per_sample=t.long().contiguous())
+            self._step_update(mean, eps, None, t_per_sample=t.long().contiguous(), clip_denoised=clip_denoised)
         else:
-            self._step_update(mean, eps, None, step_host=int(t))
+            self._step_update(mean, eps, None, step_host=int(t), clip_denoised=clip_denoised)
         return mean, self._coef('posterior_log_variance_clipped', t, x)
 
     @torch.no_grad()
     def _p_sample(self, x, t, clip_denoised=True, repeat_noise=False, condition_x=None, noise=None):
         """One reverse step; returns a new tensor (x is left untouched, as in the reference).  The public `p_sample`
         of each variant (model/{sr3,ddpm}_modules/diffusion.py) carries the reference's own parameter list."""
-        if not clip_denoised:
-            raise NotImplementedError('clip_denoised=False is never used by the reference callers')
         x = x.contiguous()
         eps = self._eps(x, t, condition_x)
         if noise is None:
@@ -165,9 +162,9 @@ class EngineDiffusion(nn.Module):
                     noise = torch.randn_like(x)
         out = x.clone()
         if torch.is_tensor(t):
-            self._step_update(out, eps, noise, t_per_sample=t.long().contiguous())
+            self._step_update(out, eps, noise, t_per_sample=t.long().contiguous(), clip_denoised=clip_denoised)
         else:
-            self._step_update(out, eps, noise, step_host=int(t))
+            self._step_update(out, eps, noise, step_host=int(t), clip_denoised=clip_denoised)
         return out
 
     # ---- the reverse loop ------------------------------------------------------------------------

@@ -72,6 +72,7 @@ SIGNATURES = {
     'sr3_unet_forward': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _I, _P]),
     'sr3_unet_forward_profile': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _I, _P, _I, _P, _P, _P, _P]),
     'sr3_p_sample_step': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    'sr3_p_sample_step_ex': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'sr3_step_decrement': (_I, [_P, _P]),
     'sr3_q_sample': (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     'sr3_train_workspace_bytes': (_Z, [_P, _I, _I]),

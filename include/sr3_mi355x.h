@@ -165,6 +165,12 @@ int sr3_p_sample_step(float* x_nchw, const float* eps_nchw, const float* z_nchw,
                       const float* tab_b, const float* tab_c1, const float* tab_c2, const float* tab_sigma,
                       const int* step_dev, const int64_t* t_per_sample, int step_host, int batch,
                       int elems_per_image, void* stream);
+/* The same update with the reference's `clip_denoised` switch (p_mean_variance, model/sr3_modules/diffusion.py:162-163,
+ * model/ddpm_modules/diffusion.py:184-185): clip_denoised == 0 skips the clamp of x0; != 0 is sr3_p_sample_step. */
+int sr3_p_sample_step_ex(float* x_nchw, const float* eps_nchw, const float* z_nchw, const float* tab_a,
+                         const float* tab_b, const float* tab_c1, const float* tab_c2, const float* tab_sigma,
+                         const int* step_dev, const int64_t* t_per_sample, int step_host, int batch,
+                         int elems_per_image, int clip_denoised, void* stream);
 /* *step_dev -= 1 on the stream (loop counter of p_sample_loop, diffusion.py:193, for graph replay) */
 int sr3_step_decrement(int* step_dev, void* stream);
 

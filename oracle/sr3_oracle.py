@@ -281,7 +281,7 @@ def schedule_tables(schedule_opt):
     )
 
 
-def p_sample_update(tab, x, eps, t, z):
+def p_sample_update(tab, x, eps, t, z, clip_denoised=True):
     """The elementwise tail of p_mean_variance + p_sample for one integer step t.
 
     sr3 diffusion.py:141-149 (predict_start_from_noise, q_posterior), :162-163 (clamp),
@@ -289,14 +289,15 @@ def p_sample_update(tab, x, eps, t, z):
     """
     T = lambda name: torch.tensor(tab[name][t], dtype=torch.float32)
     x0 = T('sqrt_recip_alphas_cumprod') * x - T('sqrt_recipm1_alphas_cumprod') * eps
-    x0 = x0.clamp(-1., 1.)
+    if clip_denoised:
+        x0 = x0.clamp(-1., 1.)
     mean = T('posterior_mean_coef1') * x0 + T('posterior_mean_coef2') * x
     if t > 0:
         return mean + z * (0.5 * T('posterior_log_variance_clipped')).exp()
     return mean + torch.zeros_like(x)
 
 
-def p_sample(sd, desc, tab, x, t, z, condition_x=None):
+def p_sample(sd, desc, tab, x, t, z, condition_x=None, clip_denoised=True):
     """One reverse step with injected noise z.  sr3 diffusion.py:151-174 / ddpm :175-198."""
     b = x.shape[0]
     if desc['variant'] == 'sr3':
@@ -305,7 +306,7 @@ def p_sample(sd, desc, tab, x, t, z, condition_x=None):
         level = torch.full((b,), t, dtype=torch.long, device=x.device)
     inp = torch.cat([condition_x, x], dim=1) if condition_x is not None else x
     eps = unet_forward(sd, desc, inp, level)
-    return p_sample_update(tab, x, eps, t, z)
+    return p_sample_update(tab, x, eps, t, z, clip_denoised)
 
 
 def p_sample_loop(sd, desc, tab, x_in, x_T, zs, conditional=True, continous=False):

@@ -505,6 +505,12 @@ def test_p_sample_step_bit_exact():
         torch.cuda.synchronize()
         ref = O.p_sample_update(tab, x, eps, t, z)
         assert torch.equal(xd.cpu(), ref), t
+        xd = (3.0 * x).to(d).clone()                      # clip_denoised = 0 (sr3_p_sample_step_ex), |x0| > 1 on most elements
+        L.check(lib.sr3_p_sample_step_ex(L.ptr(xd), L.ptr(ed), L.ptr(zd), *[L.ptr(t_) for t_ in tabs], None,
+                                         None, t, B, 3 * 16 * 16, 0, G.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(xd.cpu(), O.p_sample_update(tab, 3.0 * x, eps, t, z, clip_denoised=False)), t
+        assert not torch.equal(xd.cpu(), O.p_sample_update(tab, 3.0 * x, eps, t, z))
     # per-sample t (DDPM API) and device step counter
     tps = torch.tensor([0, 5, 49], dtype=torch.long)
     xd = x.to(d).clone()

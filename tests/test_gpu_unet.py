@@ -105,6 +105,34 @@ def test_p_sample_steps(name):
     assert torch.equal(xs.cpu(), torch.from_numpy(g['step/x']))     # input untouched
 
 
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_p_sample_without_clipping(name):
+    """The reference's `clip_denoised=False` branch (sr3 diffusion.py:162-163, ddpm :184-185) through the drop-in's
+    p_mean_variance / p_sample, against the reference's own outputs (tests/golden/noclip.npz) on inputs where the clamp bites."""
+    import os
+    import numpy as np
+    from helpers import GOLDEN
+    m, g, sd = build(name)
+    d = G.dev()
+    n = np.load(os.path.join(GOLDEN, 'noclip.npz'))
+    cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']).to(d)
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    x = torch.from_numpy(n[name + '/x']).to(d)
+    T = int(g['meta/T'])
+    for t in sorted({T - 1, T // 2, 0}):
+        tt = t if DESCS[name]['variant'] == 'sr3' else torch.full((x.shape[0],), t, dtype=torch.long, device=d)
+        kw = dict(condition_x=sr) if cond else {}
+        ret = m.netG.p_mean_variance(x=x, t=tt, clip_denoised=False, **kw)
+        assert len(ret) == (2 if DESCS[name]['variant'] == 'sr3' else 3)          # the DDPM class also returns the variance
+        scale = max(1.0, float(np.abs(n['%s/mean/%d' % (name, t)]).max()))
+        G.assert_close(ret[0].cpu(), torch.from_numpy(n['%s/mean/%d' % (name, t)]), tol=2e-5 * scale, what='%s mean %d' % (name, t))
+        r = m.netG.p_sample(x, tt, clip_denoised=False, noise=zs[t], **kw)
+        G.assert_close(r.cpu(), torch.from_numpy(n['%s/step/%d' % (name, t)]), tol=2e-5 * scale, what='%s step %d' % (name, t))
+        clipped = m.netG.p_mean_variance(x=x, t=tt, clip_denoised=True, **kw)[0]
+        assert (clipped.cpu() - torch.from_numpy(n['%s/mean/%d' % (name, t)])).abs().max() > 1e-3
+
+
 @pytest.mark.parametrize('name', NAMES)
 def test_reverse_loop_injected_noise(name):
     m, g, sd = build(name)

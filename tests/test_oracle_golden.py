@@ -66,6 +66,29 @@ def test_p_sample_steps_and_loop(name):
 
 
 @pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_p_sample_without_clipping(name):
+    """`clip_denoised=False` (sr3 diffusion.py:162-163, ddpm :184-185) against the reference's own outputs on inputs where
+    the clamp would bite (tests/golden/noclip.npz, oracle/make_golden_noclip.py)."""
+    import os
+    from helpers import GOLDEN
+    g, sd = load_golden(name)
+    n = np.load(os.path.join(GOLDEN, 'noclip.npz'))
+    d = DESCS[name]; tab = O.schedule_tables(SCHEDS[name]); cond = CONDITIONAL[name]
+    sr = torch.from_numpy(g['loop/sr']); zs = torch.from_numpy(g['loop/zs'])
+    x = torch.from_numpy(n[name + '/x'])
+    T = tab['num_timesteps']
+    with torch.no_grad():
+        for t in sorted({T - 1, T // 2, 0}):
+            kw = dict(condition_x=sr if cond else None)
+            mean = O.p_sample(sd, d, tab, x, t, torch.zeros_like(x), clip_denoised=False, **kw)
+            close(mean.numpy(), n['%s/mean/%d' % (name, t)])
+            step = O.p_sample(sd, d, tab, x, t, zs[t], clip_denoised=False, **kw)
+            close(step.numpy(), n['%s/step/%d' % (name, t)])
+            clipped = O.p_sample(sd, d, tab, x, t, torch.zeros_like(x), **kw)
+            assert np.abs(clipped.numpy() - n['%s/mean/%d' % (name, t)]).max() > 1e-3       # the switch matters here
+
+
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
 def test_p_losses(name):
     g, sd = load_golden(name)
     d = DESCS[name]; tab = O.schedule_tables(SCHEDS[name]); cond = CONDITIONAL[name]

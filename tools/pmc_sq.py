@@ -47,7 +47,7 @@ def main():
                 if c in avg:
                     rec[k2] = avg[c] / avg['SQ_WAVE_CYCLES']
         out[name] = rec
-    att = [v for k, v in out.items() if 'k_attention<' in k]
+    att = [v for k, v in out.items() if 'k_attention' in k and 'bwd' not in k]     # k_attention<..> / k_attention_v2<..>
     if att:
         out['attention'] = max(att, key=lambda v: v['dispatches'])
     json.dump(out, open(prefix + '_sq_counters.json', 'w'), indent=1)

@@ -1,10 +1,11 @@
 #!/bin/bash
-# One GPU-box pass that produces what profiles/ holds for a round: smoke, the default bench line, the other BASELINE.json
-# configurations through bench.py --config, rocprofv3 kernel statistics of the sampling leg and of a training run, and the
-# counter passes (FETCH_SIZE, WRITE_SIZE, SQ set -- each in its own run, --kernel-trace only).  Usage (through gpurun):
-#   bash tools/round_profile.sh <tag> [--with-tests]
+# One GPU-box pass that produces what profiles/ holds for a round: smoke, the default bench line (headline + other_configs
+# + training + baselines), rocprofv3 kernel statistics of the sampling leg and of a training run, the counter passes
+# (FETCH_SIZE, WRITE_SIZE, SQ set -- each in its own run, --kernel-trace only), the per-launch table of the forward and the
+# stock PyTorch-ROCm kernel statistics AFTER a MIOpen warm-up run (find results cached: no naive_conv_* find kernels).
+# Usage (through gpurun):   bash tools/round_profile.sh <tag> [--with-tests] [--quick]
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -14,24 +15,26 @@ if [ "${2:-}" = "--with-tests" ]; then
 fi
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-Q="--no-cpu-baseline --no-torch-baseline --train-steps 0 --no-split-leg"
+Q="--no-cpu-baseline --no-torch-baseline --train-steps 0 --no-split-leg --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 200 --warmup 5 $Q > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/sq.err
 python tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/$TAG > $OUT/pmc.log 2>&1
 python tools/pmc_sq.py $OUT/sq $OUT/$TAG >> $OUT/pmc.log 2>&1
+python tools/op_table.py > $OUT/op_table.txt 2> $OUT/op_table.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python tools/gpu_probe.py --train 64 > $OUT/train_probe.log 2>&1
-python bench.py --config sr3_64_512 --steps 200 --warmup 3 --train-steps 3 --no-split-leg --no-torch-baseline > $OUT/bench_sr3_64_512.json 2> $OUT/bench_sr3_64_512.err
-python bench.py --config ddpm_128 --steps 400 --warmup 5 --train-steps 5 --no-split-leg --no-torch-baseline > $OUT/bench_ddpm_128.json 2> $OUT/bench_ddpm_128.err
-# the multi-rank entry paths on this 1-GPU box: collective path forced on one rank, the launcher form the driver uses, and the
-# refusal of --gpus 2 with one visible device
-D="--steps 20 --warmup 3 --train-steps 2 --no-cpu-baseline --no-torch-baseline --no-roofline"
-SR3_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $D > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; echo "force_dist rc=$?"
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 $D > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err; echo "torchrun rc=$?"
-python bench.py --gpus 2 $D > $OUT/bench_gpus2.json 2> $OUT/bench_gpus2.err; echo "gpus2 rc=$? (2 = refused, expected on a 1-GPU box)"
+# stock PyTorch-ROCm: first run fills MIOpen's user find-db, the profiled second run reuses it
+python tools/torch_baseline_probe.py --config sr3_16_128 --batch 16 --steps 3 > $OUT/torch_warm.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/torch_stats -o torch -- python tools/torch_baseline_probe.py --config sr3_16_128 --batch 16 --steps 5 > $OUT/torch_probe.log 2>&1
+if [ "${2:-}" != "--quick" ] && [ "${3:-}" != "--quick" ]; then
+  # the multi-rank entry paths on this 1-GPU box: collective path forced on one rank and the launcher form the driver uses
+  D="--steps 20 --warmup 3 --train-steps 2 --no-cpu-baseline --no-torch-baseline --no-roofline --no-other-configs"
+  SR3_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $D > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err; echo "force_dist rc=$?"
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 $D > $OUT/bench_torchrun1.json 2> $OUT/bench_torchrun1.err; echo "torchrun rc=$?"
+fi
 grep -h "train_step" $OUT/train_probe.log | cut -c1-260
-for f in $OUT/bench.json $OUT/bench_sr3_64_512.json $OUT/bench_ddpm_128.json $OUT/bench_force_dist.json $OUT/bench_torchrun1.json; do cut -c1-260 $f; echo; done
+for f in $OUT/bench.json; do cut -c1-400 $f; echo; done
 # keep the merged-back payload small: the per-dispatch traces are not needed, the statistics and counter summaries are
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +4M -delete
