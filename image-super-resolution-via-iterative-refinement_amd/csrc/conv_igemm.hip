@@ -336,7 +336,6 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
     }
   }
-  if (tile_cfg == 12 && ksplit != 0) return;
   if (tile_cfg == 0 && p.ksize == 1) tile_cfg = 3;   // 1x1 convs: the 64x64 tile measured fastest on every layer shape of the
                                                      // BASELINE networks (76-81 vs 58-64 TF at 16x16, 78 vs 69 at 128x128)
   if (tile_cfg == 0) {
@@ -350,21 +349,6 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       const TileCfg c = kCfgs[order[k]];
       if ((long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn) >= 448) { tile_cfg = order[k]; break; }
     }
-  }
-  if (ksplit == 0 && tile_cfg == 12) {
-    // 1x1 GEMM kernel: two 8-wave workgroups per CU; a split keeps >= 4 chunks (128 input channels)
-    const long tiles = gemm1x1_workgroups(p);
-    const int units = gemm1x1_chunks(p);
-    int ks = 1;
-    if (tiles < 384) {
-      ks = (int)((512 + tiles - 1) / tiles);
-      const int cap = units / 4 > 1 ? units / 4 : 1;
-      if (ks > cap) ks = cap;
-      if (ks > 8) ks = 8;
-    }
-    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;
-    ksplit = ks;
-    return;
   }
   if (ksplit == 0 && tile_cfg == 11) {
     // Winograd kernel: one 8-wave workgroup per CU, so one full round of 256 is the target; a split keeps >= 4 chunks
@@ -462,7 +446,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   conv_pick(p, tile_cfg, ksplit);
   p.ksplit = ksplit;
-  if (p.ostat && ksplit == 1 && (tile_cfg < 5 || tile_cfg == 12)) { set_error("conv: fused output statistics need the halo kernel or split-K"); return SR3_E_UNSUPPORTED; }
+  if (p.ostat && ksplit == 1 && (tile_cfg < 5)) { set_error("conv: fused output statistics need the halo kernel or split-K"); return SR3_E_UNSUPPORTED; }
   if (p.ostat && ksplit > 1 && splitk_rows_per_block(p, true) == 0) { set_error("conv: Ho*Wo does not allow fused split-K statistics"); return SR3_E_UNSUPPORTED; }
   { static const char* e = getenv("SR3_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (ksplit > 1) {
@@ -474,9 +458,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   const bool k3 = p.ksize == 3;
   if (p.x2_w && (tile_cfg < 5 || tile_cfg == 11 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
   if (p.x2_w && ((p.x2_C0 & 3) || (p.x2_C1 & 3) || !p.x2_src0 || (p.x2_C1 > 0 && !p.x2_src1))) { set_error("conv: bad x2 segment"); return SR3_E_BADARG; }
-  if (tile_cfg == 12) {
-    rc = gemm1x1_forward(p, p.wino_u, st);
-  } else if (tile_cfg == 11) {
+  if (tile_cfg == 11) {
     rc = conv3x3_wino_forward(p, p.wino_u, st);
   } else if (tile_cfg >= 5) {
     HaloGeom g;

@@ -240,19 +240,6 @@ static int build_structure(sr3_plan* P) {
         if (L.kind == 1) { reg(L.res.c1_w, L.res.cout, L.res.cin); reg(L.res.c2_w, L.res.cout, L.res.cout); }
         else if (L.kind == 3) reg(L.w, L.cout, L.cin);
       }
-    // fragment-major copies of the 1x1 weights (res_conv, attention qkv / out) for the GEMM kernel
-    auto reg1 = [&](size_t w, int Cout, int Cin) {
-      if (Cin & 3) return;
-      P->derived.push_back({w, Cout, -Cin, dcur});       // Cin < 0 marks a 1x1 entry
-      P->derived_of[w] = dcur;
-      dcur += gemm1x1_weight_floats(Cout, Cin);
-    };
-    for (auto* v : {&P->downs, &P->mid, &P->ups})
-      for (auto& L : *v)
-        if (L.kind == 1) {
-          if (L.res.has_rc) reg1(L.res.rc_w, L.res.cout, L.res.cin);
-          if (L.res.attn) { reg1(L.res.qkv_w, 3 * L.res.cout, L.res.cout); reg1(L.res.ao_w, L.res.cout, L.res.cout); }
-        }
     P->derived_floats = dcur;
   }
 
@@ -418,9 +405,6 @@ struct Builder {
     }
     if (wino_ok(c, w, q0 >= 0, o.has_drop)) {
       o.tile_cfg = 11;
-      o.wino_off = P->derived_of[w];
-    } else if (P->gemm1x1 && P->tile_cfg == 0 && gemm1x1_fits(c) && P->derived_of.count(w)) {
-      o.tile_cfg = 12;
       o.wino_off = P->derived_of[w];
     }
     conv_pick(c, o.tile_cfg, o.ksplit);
@@ -715,11 +699,11 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
           c.x2_w = params + o.p2;
           c.x2_bias = params + o.p3;
         }
-        if (o.tile_cfg == 11 || o.tile_cfg == 12) {
+        if (o.tile_cfg == 11) {
           if (!P->derived_ptr) { set_error("the plan's derived (Winograd) weights are not bound: call sr3_plan_bind_derived + sr3_plan_prepare_derived"); return SR3_E_BADARG; }
           // stale filters must fail loudly, not compute with the previous weights: the buffer has to have been prepared from
           // THIS arena, under the current options, and not invalidated since (sr3_plan_invalidate_derived after an optimizer step)
-          if (P->derived_from != params || P->derived_opts != P->gemm1x1) {
+          if (P->derived_from != params) {
             set_error("the plan's derived (Winograd) weights are stale or were prepared from another arena: call sr3_plan_prepare_derived");
             return SR3_E_BADARG;
           }
@@ -965,7 +949,6 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
-  else if (!strcmp(key, "gemm1x1")) slot = &plan->gemm1x1;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
@@ -1007,14 +990,10 @@ int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) 
   if (!plan || !params) { set_error("null argument"); return SR3_E_BADARG; }
   if (!plan->derived_ptr) { set_error("no derived buffer bound"); return SR3_E_BADARG; }
   for (const auto& d : plan->derived) {
-    if (d.Cin < 0 && !plan->gemm1x1) continue;
-    const int rc = d.Cin < 0
-        ? gemm1x1_transform_weights(params + d.w, d.Cout, -d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream))
-        : wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
+    const int rc = wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
   plan->derived_from = params;
-  plan->derived_opts = plan->gemm1x1;
   return SR3_OK;
 }
 
@@ -1145,18 +1124,6 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
   if (tile_cfg == 11 && (ksize != 3 || stride != 1)) { set_error("conv: the Winograd kernel does not fit this problem (3x3 stride 1 only)"); return SR3_E_UNSUPPORTED; }
-  if (tile_cfg == 12) {
-    // 1x1 GEMM through the per-op entry: fragment-major weights derived here, behind the split-K slabs in `scratch`
-    if (!gemm1x1_fits(c)) { set_error("conv: the 1x1 GEMM kernel does not fit this problem"); return SR3_E_UNSUPPORTED; }
-    const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
-    const size_t ub = gemm1x1_weight_floats(Cout, c.C0 + c.C1) * sizeof(float);
-    if (!scratch || scratch_bytes < slab + ub) { set_error("conv: 1x1 GEMM scratch too small (%zu < %zu)", scratch_bytes, slab + ub); return SR3_E_NOMEM; }
-    float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
-    const int rc = gemm1x1_transform_weights(w, Cout, c.C0 + c.C1, u, static_cast<hipStream_t>(stream));
-    if (rc) return rc;
-    c.wino_u = u;
-    scratch_bytes = slab;
-  }
   if (tile_cfg == 11) {
     // Winograd form through the per-op entry: the transformed filters are derived here, behind the split-K slabs in
     // `scratch` (sr3_conv_scratch_bytes accounts for them); a plan keeps them in its derived buffer instead.
@@ -1224,10 +1191,6 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
   ConvParams c;
   memset(&c, 0, sizeof(c));
   c.B = B; c.Ho = Ho; c.Wo = Wo; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
-  if (tile_cfg == 12) {
-    c.Hs = Ho; c.Ws = Wo; c.stride = 1;
-    return conv_splitk_bytes(c, tile_cfg, ksplit) + gemm1x1_weight_floats(Cout, Cin) * sizeof(float);
-  }
   if (tile_cfg == 11) {      // Winograd: the geometry (hence the split) needs the stride-1 input dims; + the derived filters
     c.Hs = Ho; c.Ws = Wo; c.stride = 1;
     return conv_splitk_bytes(c, tile_cfg, ksplit) + wino_weight_floats(Cout, Cin) * sizeof(float);

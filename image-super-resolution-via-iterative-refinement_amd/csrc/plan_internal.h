@@ -101,7 +101,6 @@ struct sr3_plan {
   int fin_cin = 0, out_ch = 0;
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
-  int gemm1x1 = 0;           // opt-in experiment: 1x1 convs on the fragment-major-weights GEMM kernel (gemm1x1.hip); measured
                              // 68 TF vs 72 TF for the im2col kernel's 64x64 tile on this network's layers, so off by default
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
@@ -112,7 +111,6 @@ struct sr3_plan {
   float* derived_ptr = nullptr;
   size_t derived_bound_bytes = 0;
   const float* derived_from = nullptr;   // the arena sr3_plan_prepare_derived last ran on (null: never / invalidated)
-  int derived_opts = 0;                  // ... and the option state it ran under (the 1x1 entries are skipped when gemm1x1 is off)
   int loss_l2 = 0;           // training loss: 0 = L1 (sum), 1 = L2 (sum)  (set_loss, diffusion.py:84-90)
   // compiled forward
   int built_batch = -1;

@@ -97,8 +97,7 @@ struct ConvParams {
   // single-source, non-upsampled inputs (block2's input is never a concat).
   unsigned drop_seed, drop_thresh;
   float drop_scale;
-  // tile_cfg 11 (Winograd) / 12 (1x1 GEMM): this conv's derived weights in fragment-major order (conv3x3_wino.hip,
-  // gemm1x1.hip)
+  // tile_cfg 11 (Winograd): this conv's transformed filters in fragment-major order (conv3x3_wino.hip)
   const float* wino_u;
 };
 
@@ -156,14 +155,6 @@ int wino_chunks(const ConvParams& p);
 size_t wino_weight_floats(int Cout, int Cin);
 int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st);
 int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st);
-
-// 1x1 convolutions as an NT GEMM with fragment-major weights from the derived buffer (gemm1x1.hip): tile_cfg 12
-bool gemm1x1_fits(const ConvParams& p);
-long gemm1x1_workgroups(const ConvParams& p);
-int gemm1x1_chunks(const ConvParams& p);
-size_t gemm1x1_weight_floats(int Cout, int Cin);
-int gemm1x1_transform_weights(const float* w, int Cout, int Cin, float* gfrag, hipStream_t st);
-int gemm1x1_forward(const ConvParams& p, const float* gfrag, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
 // partial per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]:

@@ -213,10 +213,6 @@ def test_plan_launch_list_no_gpu():
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('split_bf16', 0)
     assert p.op_list(16) == ops
-    # opt-in experiment: the fragment-major-weights 1x1 GEMM kernel (tile 12) takes over every 1x1 conv
-    p.set_option('gemm1x1', 1)
-    assert all((o['tile_cfg'] == 12) == (o['ksize'] == 1) for o in p.op_list(16) if o['kind'] == 50)
-    p.set_option('gemm1x1', 0)
     # batch 1: everything is small-M
     assert all(o['tile_cfg'] != 9 or o['h_out'] >= 128 for o in p.op_list(1) if o['kind'] == 50)
 

@@ -131,7 +131,7 @@ def _make_case(case, seed=1):
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2), (5, 1), (6, 1), (5, 2),
                                              (6, 2), (7, 1), (8, 1), (7, 2), (9, 1), (10, 1), (9, 2), (10, 3),
-                                             (11, 1), (11, 2), (11, 0), (12, 1), (12, 2), (12, 0)])
+                                             (11, 1), (11, 2), (11, 0)])
 def test_conv(case, tile_cfg, ksplit):
     src0, src1, w, kw = _make_case(case)
     total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]

@@ -190,10 +190,10 @@ def test_engine_refuses_cpu():
 
 
 def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
-    """The Winograd / 1x1-GEMM filters live in a derived buffer.  (1) The C ABI refuses a forward on filters it was told are
+    """The Winograd filters live in a derived buffer.  (1) The C ABI refuses a forward on filters it was told are
     stale (sr3_plan_invalidate_derived: what the fused Adam step's caller does) or that were prepared from another arena,
     instead of silently computing with the previous weights.  (2) Toggling a plan option that changes the buffer's content
-    (gemm1x1) AFTER a forward rebuilds it: the output still matches the golden eps (the cache key of
+    (winograd off and on again) AFTER a forward keeps the output on the golden eps (the cache key of
     EngineUNet.ensure_derived includes the plan generation)."""
     import ctypes as C
     from sr3_hip import lib as L, engine as E
@@ -222,7 +222,8 @@ def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
         E.unet_forward(un.plan, un.arena.data, un.freq, un._ws, x, noise_level=t)
     G.assert_close(un(x, t).cpu(), ref, what='after weights_changed')
     # (2) option toggle after a forward
-    un.plan.set_option('gemm1x1', 1)
-    G.assert_close(un(x, t).cpu(), ref, what='gemm1x1 on')
-    un.plan.set_option('gemm1x1', 0)
-    G.assert_close(un(x, t).cpu(), ref, what='gemm1x1 off again')
+    un.plan.set_option('winograd', 0)
+    assert not any(o['tile_cfg'] == 11 for o in un.plan.op_list(x.shape[0]))
+    G.assert_close(un(x, t).cpu(), ref, what='winograd off')
+    un.plan.set_option('winograd', 1)
+    G.assert_close(un(x, t).cpu(), ref, what='winograd on again')

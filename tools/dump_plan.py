@@ -16,7 +16,7 @@ KIND = {10: 'embed + FiLM rows', 20: 'input conv (NCHW -> NHWC)', 30: 'GroupNorm
         50: 'conv', 60: 'attention', 70: 'output block (NHWC -> NCHW)'}
 TILE = {1: 'im2col 128x128', 2: 'im2col 128x64', 3: 'im2col 64x64', 4: 'im2col 64x128', 5: 'halo 128x128', 6: 'halo 256x64',
         7: 'halo 128x128 split-bf16', 8: 'halo 256x64 split-bf16 (8 waves)', 9: 'halo 256x128 (8 waves)',
-        10: 'halo 256x128 split-bf16 (8 waves)', 11: 'Winograd F(2x2,3x3) 64 tiles x 64 (8 waves)', 12: '1x1 GEMM 128x128 (8 waves)'}
+        10: 'halo 256x128 split-bf16 (8 waves)', 11: 'Winograd F(2x2,3x3) 64 tiles x 64 (8 waves)'}
 
 
 def main():
