@@ -335,7 +335,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
              155: 'k_conv3x3_halo<2,2,false,false,1,2>', 157: 'k_conv3x3_halo<2,2,true,false,1,2>',
              156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
              355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
-             455: 'k_conv3x3_wino'}
+             455: 'k_conv3x3_wino<0>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -375,7 +375,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
     # filters once per launch), from the plan's own launch list
     alg_bytes = None
     try:
-        ops = [o for o in plan.op_list(B) if o['kind'] == 5 and o['tile_cfg'] == 11] if is_wino else []
+        ops = [o for o in plan.op_list(B) if o['kind'] == 50 and o['tile_cfg'] == 11] if is_wino else []
         if ops:
             tot = 0.0
             for o in ops:
