@@ -28,7 +28,8 @@
 //      workgroup, so LDS would add nothing but a copy).
 // Epilogue: each wave folds its two columns with A (register adds), the rows are combined through LDS in a FIXED order
 // (bitwise reproducible), then bias / FiLM / residual / fused GroupNorm statistics / 16-byte NHWC stores as in the halo
-// kernel.  Split-K over chunks writes output-domain slabs for k_splitk_reduce.
+// kernel.  Split-K over chunks writes output-domain slabs for k_splitk_reduce.  Train-mode dropout (block2's conv): the DROP
+// instantiation masks the activated input in the staging step.
 //
 // U = G g G^T is derived from the OHWI weights by k_wino_weights whenever the weights change (plan-level "derived"
 // buffer, 16/9 of the 3x3 weights' size); it is never part of a state dict.
@@ -151,7 +152,10 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 //   epilogue:  [next tile's GroupNorm pairs + bias + FiLM]  [this tile's residual, both rounds]   ... round 0 ...
 //              [next tile's raw chunks 0 and 1]             ... round 1 ...
 //   prologue:  [U fragments of chunk 0]  stage chunks 0, 1  [raw chunk 2]
-template <int DBG>
+// DROP: train-mode dropout between the activation and the conv (nn.Dropout of Block, unet.py:86): the staged element with NHWC
+// index i of the (single, non-upsampled) source is kept iff hash32(i * 0x9E3779B9 + seed) >= thresh and scaled by 1 / (1 - p),
+// exactly as conv3x3_halo.hip does -- the mask applies to the activated input BEFORE the transform, so it fits the staging step.
+template <int DBG, bool DROP>
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
   extern __shared__ f32x4 smem_v[];
@@ -262,6 +266,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           v.z = fmaf(v.z, ssb.x, ssb.y);
           v.w = fmaf(v.w, ssb.z, ssb.w);
           if (p.act == 2) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
+          if (DROP) {                                       // single source, no upsampling (host): linear NHWC index
+            const unsigned i0 = (unsigned)(hpix[j] * p.C0 + chunk * WCK + kq * 4);
+            v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
+            v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
+            v.z *= drop_mask(p.drop_seed, i0 + 2, p.drop_thresh, p.drop_scale);
+            v.w *= drop_mask(p.drop_seed, i0 + 3, p.drop_thresh, p.drop_scale);
+          }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
         int hi = hinfo[j];
@@ -696,7 +707,8 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   WinoGeom g;
   if (!wino_geometry(p, &g)) { set_error("conv: the Winograd kernel does not fit this problem"); return SR3_E_UNSUPPORTED; }
   if (!ufrag) { set_error("conv: Winograd needs the transformed weights"); return SR3_E_BADARG; }
-  if (p.x2_w || p.drop_thresh != 0) { set_error("conv: the Winograd kernel has no fused 1x1 segment / dropout form"); return SR3_E_UNSUPPORTED; }
+  if (p.x2_w) { set_error("conv: the Winograd kernel has no fused 1x1 segment"); return SR3_E_UNSUPPORTED; }
+  if (p.drop_thresh != 0 && (p.C1 != 0 || p.ups != 0 || p.act == 0)) { set_error("conv: dropout needs a single-source, non-upsampled, activated input"); return SR3_E_UNSUPPORTED; }
   const int nch = wino_chunks(p);
   if ((nch + p.ksplit - 1) / p.ksplit > W_MAX_CK) { set_error("conv: the Winograd kernel takes at most %d input channels per K split (%d chunks over %d splits)", W_MAX_CK * WCK, nch, p.ksplit); return SR3_E_UNSUPPORTED; }
   if (p.ksplit > 1 && (long)(p.ksplit - 1) * ((nch + p.ksplit - 1) / p.ksplit) >= nch) { set_error("conv: ksplit %d leaves an empty split over %d chunks", p.ksplit, nch); return SR3_E_BADARG; }
@@ -710,14 +722,18 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const char* np = getenv("SR3_WINO_NONPERSISTENT");
   dim3 grid((unsigned)((np && np[0] == '1') ? ntiles : std::min<long>(ntiles, n_cu > 0 ? n_cu : 256)), p.ksplit);
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
-#define SR3_WINO_LAUNCH(D)                                                                                   \
-  {                                                                                                          \
-    static std::atomic<uint64_t> done{0};                                                                    \
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D>), W_SMEM, done)) return rc;  \
-    hipLaunchKernelGGL(k_conv3x3_wino<D>, grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                         \
+#define SR3_WINO_LAUNCH2(D, DR)                                                                                       \
+  {                                                                                                                   \
+    static std::atomic<uint64_t> done{0};                                                                             \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D, DR>), W_SMEM, done)) return rc;       \
+    hipLaunchKernelGGL((k_conv3x3_wino<D, DR>), grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                            \
   }
+#define SR3_WINO_LAUNCH(D) SR3_WINO_LAUNCH2(D, false)
+  if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
   switch (dbg) {
-    case 0: SR3_WINO_LAUNCH(0) break;
+    case 0:
+      if (p.drop_thresh != 0) SR3_WINO_LAUNCH2(0, true) else SR3_WINO_LAUNCH2(0, false)
+      break;
 #ifdef SR3_WINO_ABLATIONS
     case 1: SR3_WINO_LAUNCH(1) break;
     case 2: SR3_WINO_LAUNCH(2) break;
@@ -733,6 +749,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
     default: set_error("conv: SR3_WINO_DBG=%d is not built (compile with -DSR3_WINO_ABLATIONS)", dbg); return SR3_E_BADARG;
   }
 #undef SR3_WINO_LAUNCH
+#undef SR3_WINO_LAUNCH2
   SR3_LAUNCH_CHECK("k_conv3x3_wino");
   return SR3_OK;
 }

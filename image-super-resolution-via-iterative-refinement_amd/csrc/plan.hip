@@ -361,11 +361,12 @@ struct Builder {
     ops.push_back(o);
     max_cin = std::max(max_cin, Cf);
   }
-  // every 3x3 stride-1 conv the Winograd kernel covers runs on it (plan option `winograd`, default on); an explicit
-  // tile_cfg / split_bf16 keep the direct halo kernels, and so do the training plan's block2 convs (train-mode dropout
-  // and the fused res_conv segment have no Winograd form)
+  // every 3x3 stride-1 conv the Winograd kernel covers runs on it (plan option `winograd`, default on), train-mode dropout
+  // convs included; an explicit tile_cfg / split_bf16 keep the direct halo kernels (the fused res_conv segment has no
+  // Winograd form: res_conv is then its own 1x1 GEMM)
   bool wino_ok(const ConvParams& c, size_t w, bool has_x2, bool has_drop) {
-    if (!P->winograd || P->tile_cfg != 0 || P->split_bf16 || has_x2 || has_drop) return false;
+    if (!P->winograd || P->tile_cfg != 0 || P->split_bf16 || has_x2) return false;
+    if (has_drop && (c.C1 != 0 || c.ups != 0 || c.act == 0)) return false;    // the dropout form: single source, no upsampling
     if (c.ksize != 3 || c.stride != 1 || !P->derived_of.count(w)) return false;
     WinoGeom wg;
     return wino_geometry(c, &wg);
@@ -479,9 +480,10 @@ struct Builder {
     memset(&c, 0, sizeof(c));
     c.C0 = T[h1].C; c.B = B; c.Hs = T[h1].H; c.Ws = T[h1].W; c.stride = 1; c.ksize = 3;
     c.Ho = T[h1].H; c.Wo = T[h1].W; c.Cout = Cout;
-    // the Winograd kernel has no second K-segment: res_conv runs as its own 1x1 GEMM and joins as a residual
-    // (inference plan; the training plan's block2 conv carries dropout and stays on the halo kernel)
-    if (!train && wino_ok(c, w, false, false)) return false;
+    // the Winograd kernel has no second K-segment: res_conv runs as its own 1x1 GEMM and joins as a residual (round 3: also
+    // in the training plan, whose block2 conv runs the Winograd kernel's dropout instantiation)
+    c.act = 2;
+    if (wino_ok(c, w, false, train)) return false;
     int cfg = P->tile_cfg, ks = P->ksplit;
     conv_pick(c, cfg, ks);
     // under split-K the fused segment runs in the last split only (50 k-steps there vs 18 in the others for a
@@ -1178,6 +1180,17 @@ int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cou
   // same mapping p -> (threshold, scale) as sr3_train_step
   c.drop_seed = drop_seed;
   dropout_consts(drop_p, &c.drop_thresh, &c.drop_scale);
+  if (tile_cfg == 11) {       // Winograd form: the transformed filters are derived here, behind the split-K slabs (as sr3_conv_f32)
+    if (c.x2_w) { set_error("conv: the Winograd kernel has no fused 1x1 segment"); return SR3_E_UNSUPPORTED; }
+    const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
+    const size_t ub = wino_weight_floats(Cout, C0) * sizeof(float);
+    if (!scratch || scratch_bytes < slab + ub) { set_error("conv: Winograd scratch too small (%zu < %zu)", scratch_bytes, slab + ub); return SR3_E_NOMEM; }
+    float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
+    const int rc = wino_transform_weights(w, Cout, C0, u, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    c.wino_u = u;
+    scratch_bytes = slab;
+  }
   return conv_forward(c, tile_cfg, ksplit, static_cast<float*>(scratch), scratch_bytes, static_cast<hipStream_t>(stream));
 }
 unsigned sr3_dropout_threshold(float drop_p, float* scale_out) {

@@ -31,6 +31,11 @@ DROP_CASES = [
     # 256x64 tile, 64^2 layers on the 128x128 tile (the plan swaps the 8-wave 256x128 tile out for dropout convs)
     ('c3_128sq_64to64_x2_192', 1, 64, 128, 128, 64, 128, 64, False, 6, 1),
     ('c3_64sq_128to128_x2_256', 1, 128, 64, 64, 128, 128, 128, False, 5, 1),
+    # round 3: the Winograd kernel's dropout instantiation (what the training plan's block2 convs run on maps >= 16x16)
+    ('wino_16x16', 2, 64, 16, 16, 128, 0, 0, True, 11, 1),
+    ('wino_splitk', 2, 128, 16, 16, 64, 0, 0, True, 11, 2),
+    ('wino_c3_64sq_128to128', 1, 128, 64, 64, 128, 0, 0, True, 11, 1),
+    ('wino_c3_128sq_64to64', 1, 64, 128, 128, 64, 0, 0, False, 11, 1),
 ]
 
 
