@@ -236,7 +236,9 @@ int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int
 /* Train-mode `Block` (unet.py:80-91 with nn.Dropout active, :86): out = conv3x3(dropout(act(src0))) + bias + film
  *   [+ residual res0] [+ conv1x1(x2_src0|x2_src1) + x2_bias], the op sr3_train_step launches for every block2.
  * Mask: NHWC element i of the activated input is kept iff hash32(i * 0x9E3779B9 + drop_seed) >= drop_p * 2^32 and
- * scaled by 1 / (1 - drop_p) (drop_seed is the per-layer seed).  Single source, no upsampling; x2_* may be NULL. */
+ * scaled by 1 / (1 - drop_p) (drop_seed is the per-layer seed).  Single source, no upsampling; x2_* may be NULL.
+ * tile_cfg 11 runs the Winograd kernel's dropout instantiation (what sr3_train_step uses on maps >= 16x16; no x2 segment:
+ * scratch then also holds the transformed filters, as for sr3_conv_f32 -- sr3_conv_scratch_bytes accounts for them). */
 int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cout, const float* w_ohwi,
                          const float* bias, const float* ss, int act, const float* film, int film_stride,
                          const float* res0, int RC0, const float* x2_src0, int x2_C0, const float* x2_src1, int x2_C1,
