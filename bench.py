@@ -348,15 +348,24 @@ def roofline_from_profile(netG, x, cond, reps=3):
     traffic = None
     counters = None
     kname = 'sr3::' + names[dom].replace(',', ', ')
+
+    def by_kernel(table):
+        # the committed summaries carry the symbol of the tree they were recorded on: exact name first, then the same
+        # template with other trailing arguments (k_conv3x3_wino<0> was recorded before the kernel gained its DROP argument)
+        if kname in table:
+            return table[kname]
+        stem = kname[:-1] if kname.endswith('>') else kname
+        hits = [v for k, v in table.items() if isinstance(v, dict) and k.startswith(stem) and 'true' not in k[len(stem):]]
+        return hits[0] if len(hits) == 1 else None
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
         with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_hbm_traffic.json')) as f:
-            traffic = json.load(f)[kname]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
+            traffic = by_kernel(json.load(f))['hbm_bytes_per_launch']
+    except (OSError, KeyError, TypeError, ValueError):
         pass
     try:        # SQ counters of the current kernels (MFMA-busy fraction), same provenance
         with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_sq_counters.json')) as f:
             sq = json.load(f)
-        counters = {'dominant_kernel': sq.get(kname), 'attention': sq.get('attention')}
+        counters = {'dominant_kernel': by_kernel(sq), 'attention': sq.get('attention')}
     except (OSError, ValueError):
         pass
     is_wino = dom == 455
