@@ -31,7 +31,7 @@
 
 namespace sr3 {
 
-__device__ __forceinline__ float silu_h(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_h(float v) { return SR3_SILU(v); }
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -65,10 +65,17 @@ static_assert(2 * W_RAW_F <= W_EXCH_F, "the raw tiles live inside the exchange b
 constexpr int W_SMEM = (W_EXCH_F + 2 * W_CST_F) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
 static_assert(W_SMEM <= 163840, "LDS");
 
-// x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e): ~1e-7 absolute error on silu, three instructions
-// instead of libm expf's twelve -- every staged element pays for this once per output-channel block
+// x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e: ~1e-7 relative error on the exponential, one instruction
+// instead of libm expf's twelve) and the Newton-refined reciprocal of sr3_common.h -- every staged element pays for this once
+// per output-channel block.  -DSR3_WINO_EXPF (A/B builds): libm expf as everywhere else.
 __device__ __forceinline__ float silu_w(float v) {
+#if defined(SR3_EXACT_ACT) || defined(SR3_WINO_EXPF)
+  return SR3_SILU(v);
+#elif defined(SR3_FAST_RCP)
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
+#else
+  return v * sr3_rcp_nr(1.0f + __builtin_amdgcn_exp2f(fminf(v * -1.44269504088896341f, 115.0f)));
+#endif
 }
 }  // namespace
 

@@ -23,7 +23,7 @@ namespace sr3 {
 
 __device__ __forceinline__ float silu_f(float v) {
   // x * sigmoid(x); exp is the accurate libm one, reciprocal is v_rcp_f32 (1 ulp)
-  return v * __builtin_amdgcn_rcpf(1.0f + expf(-v));
+  return SR3_SILU(v);
 }
 
 template <int BM, int BN, int TAPS>
@@ -259,8 +259,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
         const size_t m = row0 + r;
         if (m >= M) break;
         f32x4 v = cb;
-        for (int s = 0; s < p.ksplit; ++s)
-          v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+        if (p.reduce_dbl) {        // uniform branch: slabs summed in double, one rounding, then the fp32 epilogue terms
+          double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+          for (int s = 0; s < p.ksplit; ++s) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+            d0 += (double)t.x; d1 += (double)t.y; d2 += (double)t.z; d3 += (double)t.w;
+          }
+          v += f32x4{(float)d0, (float)d1, (float)d2, (float)d3};
+        } else {
+          for (int s = 0; s < p.ksplit; ++s)
+            v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+        }
         const int b = (int)(m / HoWo);
         if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
         if (p.res0) {

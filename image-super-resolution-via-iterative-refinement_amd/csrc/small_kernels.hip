@@ -5,7 +5,7 @@
 
 namespace sr3 {
 
-__device__ __forceinline__ float silu_s(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_s(float v) { return SR3_SILU(v); }
 // separately rounded product / sum: the empty asm makes the value opaque so hipcc (default
 // -ffp-contract=fast) cannot fuse it into an fma -- bit parity with torch's elementwise ops.
 __device__ __forceinline__ float mul_rn(float a, float b) { float r = a * b; asm volatile("" : "+v"(r)); return r; }

@@ -24,7 +24,7 @@ double meant_double(float f) {
   return (double)f;
 }
 
-__device__ __forceinline__ float sigmoid_t(float v) { return __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+__device__ __forceinline__ float sigmoid_t(float v) { return SR3_SIGMOID(v); }
 
 // ---------------------------------------------------------------------------------------------
 // T1: activation backward + partial sums.  For the virtual concat x = (x0|x1) with u = x*scale+shift,

@@ -7,7 +7,7 @@
 
 namespace sr3 {
 
-__device__ __forceinline__ float sig_e(float v) { return __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+__device__ __forceinline__ float sig_e(float v) { return SR3_SIGMOID(v); }
 __device__ __forceinline__ float dsilu_e(float v) { const float s = sig_e(v); return s * (1.0f + v * (1.0f - s)); }
 
 // scratch layout per image b (floats): enc[inner] | hpre[4 inner] | tpre[inner] | e[inner] | de[inner]

@@ -13,7 +13,7 @@
 
 namespace sr3 {
 
-__device__ __forceinline__ float silu_w(float v) { return v * __builtin_amdgcn_rcpf(1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_w(float v) { return SR3_SILU(v); }
 
 template <int TN, int TC>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const float* __restrict__ dy,

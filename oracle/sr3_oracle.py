@@ -126,7 +126,7 @@ def block(sd, p, x, groups, drop=None):
     h = F.group_norm(x, groups, sd[p + '.block.0.weight'], sd[p + '.block.0.bias'], eps=1e-5)
     h = swish(h)
     if drop is not None:
-        h = h * dropout_mask(tuple(h.shape), *drop)
+        h = h * dropout_mask(tuple(h.shape), *drop).to(h.device)
     return F.conv2d(h, sd[p + '.block.3.weight'], sd[p + '.block.3.bias'], padding=1)
 
 
