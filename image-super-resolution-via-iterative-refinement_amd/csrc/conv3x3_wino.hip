@@ -51,8 +51,21 @@ constexpr int WROW = 18 * WRS + 8;   // LDS row stride of the raw halo (18 pixel
 constexpr int WSHIFT = 4;            // 4 floats more: with this layout the transform's ds_read_b128 (lane = tile of a 4 x 8
                                      // tile block, two channel quads) hit 16 distinct bank quads per 16-lane group
 constexpr int WNT = 512;        // threads (8 waves)
-constexpr int WHP = 324;        // raw halo pixels of one tile: 18 x 18
-constexpr int WHI = (WHP * 4 + WNT - 1) / WNT;       // raw float4 items per thread (4 channel quads per pixel)
+// Tile geometry.  NB4 = false: 64 Winograd tiles = 16 x 16 output pixels of ONE image, raw halo 18 x 18.  NB4 = true (8 x 8 maps):
+// the 64 tiles are FOUR images of 8 x 8 pixels laid out as a 2 x 2 grid of 10 x 10 halos (each image keeps its own zero
+// padding), i.e. a 20 x 20 raw block whose tile (ty, tx) starts 2 (ty >> 2) rows / 2 (tx >> 2) pixels further in.  The NB4
+// form is split-K only (bias / FiLM / residual / statistics belong to the reduce kernel) with at most 16 chunks per split (the
+// GroupNorm pairs of four images share the LDS block that holds one image's 64 chunks otherwise).
+template <bool NB4> struct WGeo {
+  static constexpr int TWp = NB4 ? 20 : 18;                 // raw halo pixels per row, and rows
+  static constexpr int WROW = TWp * WRS + 8;                // LDS row stride
+  static constexpr int SHIFT = NB4 ? 0 : WSHIFT;            // (the row-pair shift needs m blocks 8 rows apart)
+  static constexpr int MROWS = NB4 ? 10 : 8;                // raw rows between the two 32-tile MFMA blocks
+  static constexpr int WHP = TWp * TWp;                     // raw halo pixels
+  static constexpr int WHI = (WHP * 4 + WNT - 1) / WNT;     // raw float4 items per thread (4 channel quads per pixel)
+  static constexpr int RAW_F = TWp * WROW + 8;              // floats per raw buffer (two of them)
+};
+constexpr int WHP = WGeo<false>::WHP;
 constexpr int WETS = 68;        // epilogue exchange: floats per channel row of a plane (64 tiles + 4 pad)
 constexpr int WEPL = 2240;      // ... floats per plane: 32 rows x 68 + the 4-float shift of channels >= 16, padded to 16 bank quads x 35
 constexpr int W_RAW_F = 18 * WROW + 8;                // floats per raw buffer (two of them)
@@ -61,20 +74,19 @@ constexpr int W_MAX_CK = 64;                          // chunks of one workgroup
 constexpr int W_CST_F = 64 + W_MAX_CK * 2 * WCK;      // per-tile constants: bias + FiLM of 64 output channels, (scale, shift) pairs
                                                       // BEHIND the exchange block, two of them: the next tile's are written
                                                       // during the epilogue
-static_assert(2 * W_RAW_F <= W_EXCH_F, "the raw tiles live inside the exchange block's footprint");
+static_assert(2 * W_RAW_F <= W_EXCH_F && W_RAW_F == WGeo<false>::RAW_F && 2 * WGeo<true>::RAW_F <= W_EXCH_F,
+              "the raw tiles live inside the exchange block's footprint");
 constexpr int W_SMEM = (W_EXCH_F + 2 * W_CST_F) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
 static_assert(W_SMEM <= 163840, "LDS");
 
-// x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e: ~1e-7 relative error on the exponential, one instruction
-// instead of libm expf's twelve) and the Newton-refined reciprocal of sr3_common.h -- every staged element pays for this once
-// per output-channel block.  -DSR3_WINO_EXPF (A/B builds): libm expf as everywhere else.
+// x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e) and the hardware reciprocal: ~1e-7 relative error on silu,
+// three instructions instead of libm expf's twelve -- every staged element pays for this once per output-channel block.  The
+// other kernels use libm expf (SR3_SILU); the difference is below what the parity tests resolve.
 __device__ __forceinline__ float silu_w(float v) {
-#if defined(SR3_EXACT_ACT) || defined(SR3_WINO_EXPF)
+#ifdef SR3_EXACT_ACT
   return SR3_SILU(v);
-#elif defined(SR3_FAST_RCP)
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 #else
-  return v * sr3_rcp_nr(1.0f + __builtin_amdgcn_exp2f(fminf(v * -1.44269504088896341f, 115.0f)));
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 #endif
 }
 }  // namespace
@@ -162,13 +174,15 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 // DROP: train-mode dropout between the activation and the conv (nn.Dropout of Block, unet.py:86): the staged element with NHWC
 // index i of the (single, non-upsampled) source is kept iff hash32(i * 0x9E3779B9 + seed) >= thresh and scaled by 1 / (1 - p),
 // exactly as conv3x3_halo.hip does -- the mask applies to the activated input BEFORE the transform, so it fits the staging step.
-template <int DBG, bool DROP>
+template <int DBG, bool DROP, bool NB4>
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
+  using GE = WGeo<NB4>;
+  constexpr int WROW = GE::WROW, WHI = GE::WHI, WHP = GE::WHP, TWp = GE::TWp;
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
-  float* raw0 = smem;                             // [18 rows][WROW] x 2 (double buffered), inside the exchange block's footprint
-  float* raw1 = smem + W_RAW_F;
+  float* raw0 = smem;                             // [TWp rows][WROW] x 2 (double buffered), inside the exchange block's footprint
+  float* raw1 = smem + GE::RAW_F;
   float* cst = smem + W_EXCH_F;                   // per-tile constants, double buffered by tile parity: [W_CST_F] x 2
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // XCD-aware order: consecutive workgroup ids go round-robin to the 8 XCDs; give each XCD one contiguous range of the
   // (cout block major) tile list so that the U fragments of a cout block stay inside one L2 (gridDim.x is a multiple of 8
   // whenever the tile count is, so a workgroup's tiles stay on its XCD's range).
-  const int sp_tiles = g.tiles_w * g.tiles_h * p.B;
+  const int sp_tiles = g.tiles_w * g.tiles_h * g.nbt;            // nbt: batch tiles (B, or B / 4 for the four-image tile)
   const int ntiles = ((p.Cout + WBN - 1) / WBN) * sp_tiles;
   int cb = 0, tw_i = 0, th_i = 0, b0 = 0, h0 = 0, w0 = 0;
   auto decode_tile = [&](int v) {
@@ -202,15 +216,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       b0 = sp / g.tiles_h;
     }
     h0 = th_i * 16; w0 = tw_i * 16;               // one image per tile
+    if (NB4) { b0 *= 4; h0 = 0; w0 = 0; }         // ... or four whole 8 x 8 images: b0 is the first of them
   };
-  constexpr int TWp = 18;
 
   const int nch = (Cin + WCK - 1) / WCK;
   const int cper = (nch + p.ksplit - 1) / p.ksplit;
   const int c_begin = blockIdx.y * cper;
   const int c_end = min(nch, c_begin + cper);
   const int nck = c_end - c_begin;                // 1 .. W_MAX_CK (host)
-  const bool direct = p.ksplit == 1;
+  const bool direct = !NB4 && p.ksplit == 1;      // (the four-image tile is split-K only: host)
 
   // ---- raw staging items of this thread: item j covers halo pixel (tid >> 2) + 128 j, channel quad tid & 3 ----
   // hinfo packs what is tile-independent: LDS float offset (bits 0..15), halo row (16..23), halo column (24..31); -1: no item
@@ -223,16 +237,21 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     hpix[j] = -1;
     if (hp < WHP) {
       const int hy = hp / TWp, hx = hp - hy * TWp;
-      hinfo[j] = (hy * WROW + ((hy >> 1) & 1) * WSHIFT + hx * WRS) | (hy << 16) | (hx << 24);
+      hinfo[j] = (hy * WROW + ((hy >> 1) & 1) * GE::SHIFT + hx * WRS) | (hy << 16) | (hx << 24);
     }
   }
   auto set_pixels = [&]() {                       // source pixel of every staging item of the current tile (-1: zero padding)
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
-      const int hy = (hinfo[j] >> 16) & 0xff, hx = (hinfo[j] >> 24) & 0xff;
+      int hy = (hinfo[j] >> 16) & 0xff, hx = (hinfo[j] >> 24) & 0xff;
+      int bi = b0;
+      if (NB4) {                                    // halo block (hy / 10, hx / 10) of the 2 x 2 image grid
+        const int iy = hy >= 10 ? 1 : 0, ix = hx >= 10 ? 1 : 0;
+        bi += iy * 2 + ix; hy -= 10 * iy; hx -= 10 * ix;
+      }
       const int ih = h0 + hy - 1, iw = w0 + hx - 1;
       const bool ok = hinfo[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-      hpix[j] = ok ? (b0 * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
+      hpix[j] = ok ? (bi * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
     }
   };
   f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
@@ -256,7 +275,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool hvalid = chunk * WCK + kq * 4 < Cin;
     f32x4 ssa = zero, ssb = zero;
-    if (p.act != 0) {
+    if (p.act != 0 && !NB4) {
       int kq_ = kq;
       asm volatile("" : "+v"(kq_));
       const float* q = cs_ + 64 + (chunk - c_begin) * (2 * WCK) + kq_ * 8;
@@ -267,6 +286,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     for (int j = 0; j < WHI; ++j) {
       if (lrow + (WNT / 4) * j < WHP) {
         f32x4 v = r[j];
+        if (NB4 && p.act != 0) {                    // the pairs of THIS item's image: [image][chunk of the split][16 x 2]
+          const int hi_ = hinfo[j];
+          const int img = (((hi_ >> 16) & 0xff) >= 10 ? 2 : 0) + (((hi_ >> 24) & 0xff) >= 10 ? 1 : 0);
+          const float* q = cs_ + 64 + (img * nck + (chunk - c_begin)) * (2 * WCK) + kq * 8;
+          ssa = *reinterpret_cast<const f32x4*>(q);
+          ssb = *reinterpret_cast<const f32x4*>(q + 4);
+        }
         if (p.act != 0 && !(DBG & 2)) {
           v.x = fmaf(v.x, ssa.x, ssa.y);
           v.y = fmaf(v.y, ssa.z, ssa.w);
@@ -302,8 +328,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     const float* q = p.act != 0 ? p.ss + (size_t)b0 * Cin * 2 : dummy;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int ch = c_begin * WCK + (t_ + WNT * k) * 2;         // 4 floats = 2 channels
-      creg[2 + k] = *reinterpret_cast<const f32x4*>(q + (p.act != 0 && ch < Cin ? (size_t)ch * 2 : 0));
+      int e = t_ + WNT * k, img = 0;                             // 4 floats = 2 channels
+      if (NB4) {                                                 // [image 0..3][nck * 8 float4]
+        const int n8 = nck * (2 * WCK / 4);
+        img = (e >= n8 ? 1 : 0) + (e >= 2 * n8 ? 1 : 0) + (e >= 3 * n8 ? 1 : 0);
+        e -= img * n8;
+        if (t_ + WNT * k >= 4 * n8) { e = 0; img = 0; }
+      }
+      const int ch = c_begin * WCK + e * 2;
+      creg[2 + k] = *reinterpret_cast<const f32x4*>(q + (p.act != 0 && ch < Cin ? (size_t)img * Cin * 2 + (size_t)ch * 2 : 0));
     }
   };
   auto store_consts = [&](float* cs_) {
@@ -319,8 +352,11 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int e = t_ + WNT * k;
-      const int ch = c_begin * WCK + e * 2;
-      if (e < nck * (2 * WCK) / 4) *reinterpret_cast<f32x4*>(cs_ + 64 + e * 4) = (p.act != 0 && ch < Cin) ? creg[2 + k] : zero;
+      const int n8 = nck * (2 * WCK) / 4;
+      int ew = e;                                                // float4 index inside its image's block
+      if (NB4) ew = e - ((e >= n8 ? 1 : 0) + (e >= 2 * n8 ? 1 : 0) + (e >= 3 * n8 ? 1 : 0)) * n8;
+      const int ch = c_begin * WCK + ew * 2;
+      if (e < (NB4 ? 4 : 1) * n8) *reinterpret_cast<f32x4*>(cs_ + 64 + e * 4) = (p.act != 0 && ch < Cin) ? creg[2 + k] : zero;
     }
   };
 
@@ -338,8 +374,9 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   const int tl = lane & 31, hq = lane >> 5;
   const int tyl = tl >> 3, tx = tl & 7;
   const int r0 = 2 * tyl;
-  const int offa = (r0 + ra) * WROW + (((r0 + ra) >> 1) & 1) * WSHIFT + (2 * tx + wh) * WRS + hq * 4;
-  const int offb = (r0 + rb) * WROW + (((r0 + rb) >> 1) & 1) * WSHIFT + (2 * tx + wh) * WRS + hq * 4;
+  const int txo = 2 * tx + (NB4 ? 2 * (tx >> 2) : 0) + wh;          // (NB4: the right-hand images start 2 pixels further in)
+  const int offa = (r0 + ra) * WROW + (((r0 + ra) >> 1) & 1) * GE::SHIFT + txo * WRS + hq * 4;
+  const int offb = (r0 + rb) * WROW + (((r0 + rb) >> 1) & 1) * GE::SHIFT + txo * WRS + hq * 4;
   // the transform of one (m block, half chunk), split so that its six LDS reads can be in flight across an MFMA block:
   //   t_load issues the reads, t_finish does the row pass (3 FMAs) and the column pass (2 adds): va / vb = this wave's two
   //   positions, components = 4 consecutive k-steps
@@ -347,8 +384,8 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     if (DBG & 4) return;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-      da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + (m * 8 * WROW + s * WRS + kk * 8));
-      db[s] = *reinterpret_cast<const f32x4*>(rawbuf + offb + (m * 8 * WROW + s * WRS + kk * 8));
+      da[s] = *reinterpret_cast<const f32x4*>(rawbuf + offa + (m * GE::MROWS * WROW + s * WRS + kk * 8));
+      db[s] = *reinterpret_cast<const f32x4*>(rawbuf + offb + (m * GE::MROWS * WROW + s * WRS + kk * 8));
     }
   };
   auto t_finish = [&](const f32x4 (&da)[3], const f32x4 (&db)[3], f32x4& va, f32x4& vb) {
@@ -414,7 +451,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   __syncthreads();
 
   const int T = g.tiles_h * g.tiles_w;                             // statistics partials per image
-  const bool stats = direct && p.ostat != nullptr;
+  const bool stats = !NB4 && direct && p.ostat != nullptr;
   const bool has_res = direct && p.res0 != nullptr;
   const size_t Mtot = (size_t)p.B * H * W;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
@@ -515,7 +552,8 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     const int tq = ((elane >> 5) & 1) | (((elane >> 3) & 1) << 1) | ((wave & 3) << 2);   // tiles 4 tq .. 4 tq + 3 (half a tile row)
     const int ety = tq >> 1, etx0 = (tq & 1) * 4;                                       // tile row, first tile column
     const int e_cb = cb, e_b0 = b0, e_tix = th_i * g.tiles_w + tw_i, e_vtile = vtile;
-    const size_t pix0 = ((size_t)b0 * H + (h0 + 2 * ety + fp)) * W + (w0 + 2 * etx0 + fq);   // tile k of the four: + 2 k pixels
+    const size_t pix0 = NB4 ? ((size_t)(b0 + (ety >> 2) * 2 + (tq & 1)) * H + (2 * (ety & 3) + fp)) * W + fq
+                            : ((size_t)b0 * H + (h0 + 2 * ety + fp)) * W + (w0 + 2 * etx0 + fq);   // tile k of the four: + 2 k pixels
     stamp(e_vtile, 2);
     // the next tile (the last one re-fetches itself: the loads stay unconditional)
     const bool has_next = vtile + (int)gridDim.x < ntiles;
@@ -689,24 +727,28 @@ bool wino_geometry(const ConvParams& p, WinoGeom* g) {
   if (p.ksize != 3 || p.stride != 1) return false;
   const int H = p.Ho, W = p.Wo;
   if (H != (p.Hs << p.ups) || W != (p.Ws << p.ups)) return false;
-  if (W < 16 || (W % 16) != 0 || (H % 16) != 0) return false;     // 8x8 maps stay on the direct kernel (no gain measured)
-  g->TH = 16; g->TW = 16; g->NB = 1;
+  // four whole 8 x 8 images per workgroup tile (split-K only: at least two 16-channel chunks)
+  const bool nb4 = H == 8 && W == 8 && p.ups == 0 && (p.B % 4) == 0 && p.C0 + p.C1 > WCK;
+  if (!nb4 && (W < 16 || (W % 16) != 0 || (H % 16) != 0)) return false;
+  g->TH = nb4 ? 8 : 16; g->TW = g->TH; g->NB = nb4 ? 4 : 1;
   g->twt = 8; g->log_twt = 3;
-  g->tpi = 64; g->log_tpi = 6;
-  g->tiles_w = W / 16; g->tiles_h = H / 16;
-  g->HPI = WHP;
-  g->HP = WHP;
+  g->tpi = nb4 ? 16 : 64; g->log_tpi = nb4 ? 4 : 6;
+  g->tiles_w = nb4 ? 1 : W / 16; g->tiles_h = nb4 ? 1 : H / 16;
+  g->nbt = nb4 ? p.B / 4 : p.B;
+  g->HPI = nb4 ? 100 : WHP;
+  g->HP = nb4 ? 400 : WHP;
   // tile decode of the persistent kernel: shifts when the tile grid is a power of two, a magic number for / sp_tiles
   g->log_tw = ilog2x(g->tiles_w); g->log_th = ilog2x(g->tiles_h);
   g->pow2 = ((1 << g->log_tw) == g->tiles_w && (1 << g->log_th) == g->tiles_h) ? 1 : 0;
-  const unsigned long long spt = (unsigned long long)g->tiles_w * g->tiles_h * p.B;
+  const unsigned long long spt = (unsigned long long)g->tiles_w * g->tiles_h * g->nbt;
   if (spt == 0 || spt * spt * ((p.Cout + WBN - 1) / WBN) >= (1ull << 32)) return false;    // (keeps the multiply-high exact)
   g->sp_magic = spt == 1 ? 0u : (unsigned)(((1ull << 32) + spt - 1) / spt);
   return true;
 }
-int wino_stats_slices(const WinoGeom& g) { return g.tiles_h * g.tiles_w; }
+int wino_stats_slices(const WinoGeom& g) { return g.NB == 1 ? g.tiles_h * g.tiles_w : 0; }   // (four-image tile: split-K only)
+int wino_max_chunks_per_split(const WinoGeom& g) { return g.NB == 1 ? W_MAX_CK : 16; }
 long wino_workgroups(const ConvParams& p, const WinoGeom& g) {
-  return (long)((p.Cout + WBN - 1) / WBN) * g.tiles_w * g.tiles_h * p.B;
+  return (long)((p.Cout + WBN - 1) / WBN) * g.tiles_w * g.tiles_h * g.nbt;
 }
 int wino_chunks(const ConvParams& p) { return (p.C0 + p.C1 + WCK - 1) / WCK; }
 
@@ -717,7 +759,8 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (p.x2_w) { set_error("conv: the Winograd kernel has no fused 1x1 segment"); return SR3_E_UNSUPPORTED; }
   if (p.drop_thresh != 0 && (p.C1 != 0 || p.ups != 0 || p.act == 0)) { set_error("conv: dropout needs a single-source, non-upsampled, activated input"); return SR3_E_UNSUPPORTED; }
   const int nch = wino_chunks(p);
-  if ((nch + p.ksplit - 1) / p.ksplit > W_MAX_CK) { set_error("conv: the Winograd kernel takes at most %d input channels per K split (%d chunks over %d splits)", W_MAX_CK * WCK, nch, p.ksplit); return SR3_E_UNSUPPORTED; }
+  if ((nch + p.ksplit - 1) / p.ksplit > wino_max_chunks_per_split(g)) { set_error("conv: the Winograd kernel takes at most %d input channels per K split here (%d chunks over %d splits)", wino_max_chunks_per_split(g) * WCK, nch, p.ksplit); return SR3_E_UNSUPPORTED; }
+  if (g.NB != 1 && p.ksplit < 2) { set_error("conv: the four-image Winograd tile (8 x 8 maps) is split-K only"); return SR3_E_UNSUPPORTED; }
   if (p.ksplit > 1 && (long)(p.ksplit - 1) * ((nch + p.ksplit - 1) / p.ksplit) >= nch) { set_error("conv: ksplit %d leaves an empty split over %d chunks", p.ksplit, nch); return SR3_E_BADARG; }
   // persistent workgroups: one per CU (8 waves, 157 KB of LDS), each walking its share of the tile list
   static const int n_cu = [] {
@@ -729,34 +772,39 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const char* np = getenv("SR3_WINO_NONPERSISTENT");
   dim3 grid((unsigned)((np && np[0] == '1') ? ntiles : std::min<long>(ntiles, n_cu > 0 ? n_cu : 256)), p.ksplit);
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
-#define SR3_WINO_LAUNCH2(D, DR)                                                                                       \
+#define SR3_WINO_LAUNCH3(D, DR, N4)                                                                                   \
   {                                                                                                                   \
     static std::atomic<uint64_t> done{0};                                                                             \
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D, DR>), W_SMEM, done)) return rc;       \
-    hipLaunchKernelGGL((k_conv3x3_wino<D, DR>), grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                            \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D, DR, N4>), W_SMEM, done)) return rc;   \
+    hipLaunchKernelGGL((k_conv3x3_wino<D, DR, N4>), grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                        \
   }
-#define SR3_WINO_LAUNCH(D) SR3_WINO_LAUNCH2(D, false)
+#define SR3_WINO_LAUNCH2(D, DR)                                                                                       \
+  if (g.NB == 1) SR3_WINO_LAUNCH3(D, DR, false) else SR3_WINO_LAUNCH3(D, DR, true)
+#define SR3_WINO_LAUNCH(D)                                                                                            \
+  if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
+  SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
   switch (dbg) {
     case 0:
-      if (p.drop_thresh != 0) SR3_WINO_LAUNCH2(0, true) else SR3_WINO_LAUNCH2(0, false)
+      if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
       break;
 #ifdef SR3_WINO_ABLATIONS
-    case 1: SR3_WINO_LAUNCH(1) break;
-    case 2: SR3_WINO_LAUNCH(2) break;
-    case 4: SR3_WINO_LAUNCH(4) break;
-    case 8: SR3_WINO_LAUNCH(8) break;
-    case 16: SR3_WINO_LAUNCH(16) break;
-    case 32: SR3_WINO_LAUNCH(32) break;
-    case 38: SR3_WINO_LAUNCH(38) break;       // MFMA + U + epilogue only
-    case 46: SR3_WINO_LAUNCH(46) break;       // MFMA + U only
-    case 62: SR3_WINO_LAUNCH(62) break;       // bare MFMA loop
-    case 64: SR3_WINO_LAUNCH(64) break;       // phase time stamps
+    case 1: { SR3_WINO_LAUNCH(1) } break;
+    case 2: { SR3_WINO_LAUNCH(2) } break;
+    case 4: { SR3_WINO_LAUNCH(4) } break;
+    case 8: { SR3_WINO_LAUNCH(8) } break;
+    case 16: { SR3_WINO_LAUNCH(16) } break;
+    case 32: { SR3_WINO_LAUNCH(32) } break;
+    case 38: { SR3_WINO_LAUNCH(38) } break;       // MFMA + U + epilogue only
+    case 46: { SR3_WINO_LAUNCH(46) } break;       // MFMA + U only
+    case 62: { SR3_WINO_LAUNCH(62) } break;       // bare MFMA loop
+    case 64: { SR3_WINO_LAUNCH(64) } break;       // phase time stamps
 #endif
     default: set_error("conv: SR3_WINO_DBG=%d is not built (compile with -DSR3_WINO_ABLATIONS)", dbg); return SR3_E_BADARG;
   }
 #undef SR3_WINO_LAUNCH
 #undef SR3_WINO_LAUNCH2
+#undef SR3_WINO_LAUNCH3
   SR3_LAUNCH_CHECK("k_conv3x3_wino");
   return SR3_OK;
 }

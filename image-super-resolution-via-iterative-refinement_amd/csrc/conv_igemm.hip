@@ -259,17 +259,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
         const size_t m = row0 + r;
         if (m >= M) break;
         f32x4 v = cb;
-        if (p.reduce_dbl) {        // uniform branch: slabs summed in double, one rounding, then the fp32 epilogue terms
-          double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-          for (int s = 0; s < p.ksplit; ++s) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
-            d0 += (double)t.x; d1 += (double)t.y; d2 += (double)t.z; d3 += (double)t.w;
-          }
-          v += f32x4{(float)d0, (float)d1, (float)d2, (float)d3};
-        } else {
-          for (int s = 0; s < p.ksplit; ++s)
-            v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
-        }
+        for (int s = 0; s < p.ksplit; ++s)
+          v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
         const int b = (int)(m / HoWo);
         if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
         if (p.res0) {
@@ -366,6 +357,7 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     if (!wino_geometry(p, &wg)) { ksplit = 1; return; }
     const long tiles = wino_workgroups(p, wg);
     const int units = wino_chunks(p);
+    const int maxck = wino_max_chunks_per_split(wg);
     int ks = 1;
     if (tiles < 256) {
       ks = (int)((256 + tiles - 1) / tiles);
@@ -373,8 +365,9 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       if (ks > cap) ks = cap;
       if (ks > 16) ks = 16;
     }
-    if (cdiv(units, ks) > 64) ks = cdiv(units, 64);        // at most 64 chunks (1024 input channels) per split: the kernel's
-    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;   // LDS block of GroupNorm pairs
+    if (wg.NB != 1 && ks < 2 && units >= 2) ks = 2;          // the four-image tile (8 x 8 maps) has no direct epilogue
+    if (cdiv(units, ks) > maxck) ks = cdiv(units, maxck);    // chunks per split the kernel's LDS block of GroupNorm pairs holds
+    while (ks > 1 && (long)(ks - 1) * cdiv(units, ks) >= units) --ks;
     ksplit = ks;
     return;
   }

@@ -775,11 +775,11 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       memset(&g, 0, sizeof(g));
       g.C0 = o.C; g.B = B; g.Hs = x0.H << r.ups; g.Ws = x0.W << r.ups; g.stride = 1; g.ksize = r.ksize;
       g.Ho = g.Hs; g.Wo = g.Ws; g.Cout = c.C0 + c.C1;
-      max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, r.ksize == 3 ? dgrad_ksplit_for(P, g, 0) : 0));
+      max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
       {   // the data gradient of a 3x3 conv runs on the Winograd kernel where it fits: its slabs and transformed filters
         WinoGeom wg;
         if (P->winograd && r.ksize == 3 && wino_geometry(g, &wg)) {
-          max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 11, dgrad_ksplit_for(P, g, 11)));
+          max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 11, 0));
           max_wu = std::max(max_wu, wino_weight_floats(g.Cout, g.C0) * sizeof(float));
         }
       }
@@ -951,9 +951,6 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
-  else if (!strcmp(key, "dgrad_ksplit")) slot = &plan->dgrad_ksplit;
-  else if (!strcmp(key, "dgrad_dbl")) slot = &plan->dgrad_dbl;
-  else if (!strcmp(key, "dgrad_winograd")) slot = &plan->dgrad_winograd;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;

@@ -111,9 +111,6 @@ struct sr3_plan {
   float* derived_ptr = nullptr;
   size_t derived_bound_bytes = 0;
   const float* derived_from = nullptr;   // the arena sr3_plan_prepare_derived last ran on (null: never / invalidated)
-  int dgrad_ksplit = 0;      // training: split-K of the 3x3 data-gradient convs (0 = the forward heuristic), slabs summed in
-  int dgrad_winograd = 1;    // training: 3x3 data gradients on the Winograd kernel (0: the direct kernels; an A/B knob)
-  int dgrad_dbl = 0;         // double when dgrad_dbl is set (shorter fp32 accumulation chains in front of GroupNorm's backward)
   int loss_l2 = 0;           // training loss: 0 = L1 (sum), 1 = L2 (sum)  (set_loss, diffusion.py:84-90)
   // compiled forward
   int built_batch = -1;
@@ -149,7 +146,4 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid,
                 const DropCfg* drop = nullptr);
 int build_train(sr3_plan* P, int B, int cond_channels);
-// split-K of a 3x3 data-gradient conv of the training step: the larger of the forward heuristic's choice and the plan option
-// dgrad_ksplit, kept to splits of at least one full chunk each (0: leave it to conv_pick)
-int dgrad_ksplit_for(const sr3_plan* P, const ConvParams& g, int tile_cfg);
 }  // namespace sr3

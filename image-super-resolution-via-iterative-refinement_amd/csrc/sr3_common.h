@@ -13,25 +13,15 @@ namespace sr3 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// sigmoid / SiLU of the staging and activation-backward steps.  The bare hardware reciprocal (v_rcp_f32, 1 ulp) is NOT good
-// enough here: its error is one-sided for a given operand, so it does not average out over the 10^5..10^6 pixels a weight
-// gradient sums -- measured at batch 64 against float64 autograd (profiles/r04_grad_probe.txt): worst parameter-gradient error
-// 8.6e-5 with v_rcp_f32, 5.0e-7 with a correctly rounded quotient.  One Newton-Raphson step (two FMAs) brings the reciprocal to
-// within half an ulp; the exponent is clamped so that 1 + e^80 stays finite (silu(-80) = -1.4e-33 either way).
-// -DSR3_EXACT_ACT (A/B builds only): IEEE division instead.
-__device__ __forceinline__ float sr3_rcp_nr(float d) {
-  const float r = __builtin_amdgcn_rcpf(d);
-  return fmaf(r, fmaf(-d, r, 1.0f), r);
-}
+// sigmoid / SiLU of the staging and activation-backward steps: libm expf (1 ulp) and the hardware reciprocal v_rcp_f32
+// (1 ulp).  Measured against float64 autograd at batch 64 (profiles/r04_grad_probe.txt): parameter gradients are within 5e-7
+// of float64 with these, the same as with an IEEE division (-DSR3_EXACT_ACT, A/B builds only) and as stock PyTorch-ROCm.
 #ifdef SR3_EXACT_ACT
-#define SR3_SIGMOID(v) (1.0f / (1.0f + expf(fminf(-(v), 80.0f))))
-#define SR3_SILU(v) ((v) / (1.0f + expf(fminf(-(v), 80.0f))))
-#elif defined(SR3_FAST_RCP)
+#define SR3_SIGMOID(v) (1.0f / (1.0f + expf(-(v))))
+#define SR3_SILU(v) ((v) / (1.0f + expf(-(v))))
+#else
 #define SR3_SIGMOID(v) __builtin_amdgcn_rcpf(1.0f + expf(-(v)))
 #define SR3_SILU(v) ((v) * __builtin_amdgcn_rcpf(1.0f + expf(-(v))))
-#else
-#define SR3_SIGMOID(v) sr3::sr3_rcp_nr(1.0f + expf(fminf(-(v), 80.0f)))
-#define SR3_SILU(v) ((v) * sr3::sr3_rcp_nr(1.0f + expf(fminf(-(v), 80.0f))))
 #endif
 
 // ---- error plumbing (thread-local message, int codes: 0 ok, >0 hipError_t, <0 engine) ----
@@ -102,7 +92,6 @@ struct ConvParams {
   float* out;          // [B,Ho,Wo,Cout]
   float* partial;      // split-K scratch [ksplit][M][Cout] (ksplit > 1)
   int ksplit;
-  int reduce_dbl;      // split-K: the reduce kernel sums the slabs in double (the training step's data gradients)
   double* ostat;       // optional (halo kernel only): partial {sum, sumsq} of the OUTPUT, [B][T][Cout][2]
   int dbg;             // profiling ablations only (env SR3_CONV_DBG): 1 = skip MFMA, 2 = skip staging
   // Optional second K-segment (halo kernel only): a 1x1 conv of another tensor (virtual concat
@@ -166,12 +155,14 @@ struct WinoGeom {
   int twt, log_twt;      // Winograd (2x2) tiles per tile row
   int tpi, log_tpi;      // Winograd tiles per image of the workgroup tile
   int tiles_w, tiles_h;  // workgroup tiles per image
+  int nbt;               // batch tiles: B (one image per tile) or B / 4 (NB = 4: four 8 x 8 images per tile)
   int HPI, HP;           // raw halo pixels per image / per workgroup
   int log_tw, log_th, pow2;   // tile decode of the persistent kernel: tiles_w / tiles_h as shifts when both are powers of two
   unsigned sp_magic;          // ceil(2^32 / (tiles_w * tiles_h * B)): tile id / tiles-per-cout-block as a multiply-high
 };
 bool wino_geometry(const ConvParams& p, WinoGeom* g);
 int wino_stats_slices(const WinoGeom& g);
+int wino_max_chunks_per_split(const WinoGeom& g);     // 64 (1024 input channels); 16 for the four-image tile
 long wino_workgroups(const ConvParams& p, const WinoGeom& g);
 int wino_chunks(const ConvParams& p);
 size_t wino_weight_floats(int Cout, int Cin);

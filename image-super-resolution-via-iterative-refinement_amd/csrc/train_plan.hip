@@ -18,19 +18,6 @@
 
 namespace sr3 {
 
-int dgrad_ksplit_for(const sr3_plan* P, const ConvParams& g, int tile_cfg) {
-  if (P->dgrad_ksplit <= 1) return 0;
-  int cfg = tile_cfg, ks = 0;
-  conv_pick(g, cfg, ks);
-  if (cfg < 5) return 0;                                   // im2col shapes keep the heuristic
-  const int units = (g.C0 + g.C1 + (cfg == 11 ? 15 : 31)) / (cfg == 11 ? 16 : 32);
-  if (ks < P->dgrad_ksplit) ks = P->dgrad_ksplit;
-  if (ks > units) ks = units;
-  if (ks > 16) ks = 16;
-  while (ks > 1 && (long)(ks - 1) * ((units + ks - 1) / ks) >= units) --ks;
-  return ks;
-}
-
 namespace {
 struct TrainCtx {
   sr3_plan* P;
@@ -54,20 +41,18 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   memset(&c, 0, sizeof(c));
   c.src0 = g; c.C0 = Cg; c.B = X.B; c.Hs = H; c.Ws = W; c.stride = 1; c.ksize = ksize; c.Ho = H; c.Wo = W;
   c.Cout = Cin; c.w = wt; c.out = dA; c.ksplit = 1;
-  c.reduce_dbl = X.P->dgrad_dbl;
   // 3x3: Winograd F(2x2,3x3) on the flipped-transposed filters where the geometry fits (the data gradient has neither a
   // prologue nor dropout, so every 3x3 stride-1 / zero-inserted stride-2 layer with H, W multiples of 16 qualifies)
   WinoGeom wg;
-  if (X.P->winograd && X.P->dgrad_winograd && ksize == 3 && wino_geometry(c, &wg) &&
+  if (X.P->winograd && ksize == 3 && wino_geometry(c, &wg) &&
       wino_weight_floats(Cin, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
     float* wu = X.at<float>(X.P->t_wu_off);
     rc = wino_transform_weights(wt, Cin, Cg, wu, X.st);
     if (rc) return rc;
     c.wino_u = wu;
-    return conv_forward(c, 11, dgrad_ksplit_for(X.P, c, 11), X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
+    return conv_forward(c, 11, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
   }
-  return conv_forward(c, 0, ksize == 3 ? dgrad_ksplit_for(X.P, c, 0) : 0, X.at<float>(X.P->t_scratch_off),
-                      X.P->t_scratch_bytes, X.st);
+  return conv_forward(c, 0, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
 }
 
 int wgrad_call(const TrainCtx& X, ConvParams c, const float* dy, float* dw) {

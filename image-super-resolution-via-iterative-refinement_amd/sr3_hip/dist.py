@@ -35,9 +35,14 @@ def bootstrap():
     No WORLD_SIZE > 1 in the environment and no process group => (0, 1, 0) and nothing is touched.  Otherwise (torchrun /
     torch.distributed.run env: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT): the current device becomes
     `cuda:LOCAL_RANK` and a process group is created -- 'nccl' (= RCCL) bound to that device when a GPU is visible, 'gloo'
-    otherwise (CPU tests) -- unless the caller already made one.  The torch RNG of rank r is re-seeded to
-    `initial_seed + r * 1000003` so ranks draw different z / dropout seeds (numpy's global RNG, which draws the SR3
-    training timestep, is entropy-seeded per process).  `SR3_DP=0` opts out: the processes stay independent replicas;
+    otherwise (CPU tests) -- unless the caller already made one.  The torch RNG of every rank r > 0 is re-seeded to
+    `initial_seed + r * 1000003` so ranks draw different z / dropout seeds; rank 0's generator is left exactly where the
+    caller's own seeding and draws put it (re-seeding it would replay draws already made).  A script that seeds must do so
+    BEFORE its first call into the drop-in packages: a `torch.manual_seed(s)` after this point gives every rank the same
+    stream again.  (numpy's global RNG, which draws the SR3 training timestep, is entropy-seeded per process.)  On ranks
+    > 0 the loggers the reference's scripts set up (`core/logger.py:setup_logger`: the root logger and 'val', both
+    writing experiments/<name>_<time>/logs/*.log) are raised to WARNING, so the INFO stream -- option dump, l_pix lines,
+    PSNR -- is written once, by rank 0, as checkpoints and images are.  `SR3_DP=0` opts out: the processes stay independent replicas;
     `SR3_DP=force` creates the group even for WORLD_SIZE=1 and keeps the collectives on (tests)."""
     global _BOOT
     import torch.distributed as tdist
@@ -60,7 +65,9 @@ def bootstrap():
     force_collectives = force
     rank = _env_int('RANK', 0)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+    # dmabuf IPC: RCCL needs it on this driver.  Only effective if HIP is not initialised yet in this process (the image
+    # and the launcher export it anyway; this covers a bare environment)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if 'MASTER_PORT' not in os.environ:
         raise RuntimeError('WORLD_SIZE=%d but MASTER_PORT is not set: start the script with '
                            '`python -m torch.distributed.run --nproc-per-node N ...`' % world)
@@ -74,7 +81,11 @@ def bootstrap():
         tdist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
     else:
         tdist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.manual_seed(torch.initial_seed() + rank * 1000003)
+    if rank != 0:
+        torch.manual_seed(torch.initial_seed() + rank * 1000003)
+        import logging
+        for name in (None, 'base', 'val'):
+            logging.getLogger(name).setLevel(logging.WARNING)
     _BOOT = (rank, world, local)
     return _BOOT
 
@@ -262,13 +273,28 @@ class GradReducer(object):
 
 
 # ---- validation / unconditional sampling: consecutive items dealt round-robin over the ranks ----------------
-def _gather_padded(own, template_shape, world, tdist, dev):
-    """all_gather of one same-shaped tensor per rank (`own` None => zeros of template_shape)."""
-    if own is None:
-        own = torch.zeros(template_shape, dtype=torch.float32, device=dev)
-    parts = [torch.empty_like(own) for _ in range(world)]
-    tdist.all_gather(parts, own.contiguous())
-    return parts
+def _gather_ragged(own, world, tdist, dev):
+    """all_gather of one fp32 tensor per rank whose shapes may differ (or be absent: `own` None): the shapes travel
+    first, the payloads are padded to the largest one.  Returns a list of `world` tensors (None for absent ones)."""
+    meta = torch.zeros(8, dtype=torch.int64, device=_coll_device())
+    if own is not None:
+        if own.dim() > 7:
+            raise ValueError('gather: tensors of more than 7 dimensions are not supported')
+        meta[0] = own.dim()
+        meta[1:1 + own.dim()] = torch.tensor(list(own.shape), dtype=torch.int64)
+    metas = [torch.empty_like(meta) for _ in range(world)]
+    tdist.all_gather(metas, meta)
+    shapes = []
+    for m in metas:
+        m = m.tolist()
+        shapes.append(None if m[0] == 0 else [int(v) for v in m[1:1 + int(m[0])]])
+    numel = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]
+    flat = torch.zeros(max(max(numel), 1), dtype=torch.float32, device=dev)
+    if own is not None:
+        flat[:own.numel()].copy_(own.reshape(-1))
+    parts = [torch.empty_like(flat) for _ in range(world)]
+    tdist.all_gather(parts, flat)
+    return [None if sh is None else p[:n].view(sh) for p, sh, n in zip(parts, shapes, numel)]
 
 
 class ValWave(object):
@@ -292,16 +318,10 @@ class ValWave(object):
         own = None
         if rank < n:
             own = netG.super_resolution(self.conds[rank], continous)
-        # every item of a validation loader has the same shape (batch 1, fixed resolution) and rank 0 always has one:
-        # its result shape tells the item-less ranks of a ragged last wave what to contribute
-        meta = torch.zeros(6, dtype=torch.int64, device=_coll_device())
-        if own is not None:
-            meta[0] = own.dim()
-            meta[1:1 + own.dim()] = torch.tensor(list(own.shape), dtype=torch.int64)
-        tdist.broadcast(meta, 0)
-        dims = [int(v) for v in meta[1:1 + int(meta[0])].tolist()]
+        # items may differ in shape (an inference set with mixed resolutions) and a ragged last wave leaves ranks without
+        # one: shapes are gathered first, payloads padded to the largest
         dev = own.device if own is not None else self.conds[0].device
-        parts = _gather_padded(own, dims, world, tdist, dev)
+        parts = _gather_ragged(own, world, tdist, dev)
         self.results = parts[:n]
         self.continous = continous
 

@@ -180,14 +180,28 @@ def build(name, opt, batch, seed, with_train=True, scale_weights=None):
           '%.1f KB' % (os.path.getsize(path) / 1024))
 
 
-if __name__ == '__main__':
+def build_all(only=None):
+    want = lambda n: only is None or n in only
     # sr3_tiny: conditional SR3, 3 levels, attention at 8x8 (+ mid), concat seams 16+16, 16+8 ...
-    build('sr3_tiny', make_opt('sr3', 6, 8, 4, [1, 2, 2], [8], 1, 16, 8, True, 'train'),
-          batch=2, seed=1234, scale_weights=0.1)
+    if want('sr3_tiny'):
+      build('sr3_tiny', make_opt('sr3', 6, 8, 4, [1, 2, 2], [8], 1, 16, 8, True, 'train'),
+            batch=2, seed=1234, scale_weights=0.1)
     # ddpm_tiny: unconditional DDPM variant (timestep embedding, per-sample t)
-    build('ddpm_tiny', make_opt('ddpm', 3, 8, 4, [1, 2], [8], 2, 16, 6, False, 'train', lin=(1e-4, 2e-2)),
-          batch=2, seed=4321, scale_weights=0.1)
+    if want('ddpm_tiny'):
+      build('ddpm_tiny', make_opt('ddpm', 3, 8, 4, [1, 2], [8], 2, 16, 6, False, 'train', lin=(1e-4, 2e-2)),
+            batch=2, seed=4321, scale_weights=0.1)
     # sr3_seam: default 32 groups, inner 32 -> GroupNorm groups straddle the concat seam
     # (64+32 = 96 channels / 32 groups = 3 per group), attention at 8x8.
-    build('sr3_seam', make_opt('sr3', 6, 32, 32, [1, 2], [8], 1, 16, 4, True, 'train'),
-          batch=2, seed=99, with_train=False, scale_weights=0.1)
+    if want('sr3_seam'):
+      build('sr3_seam', make_opt('sr3', 6, 32, 32, [1, 2], [8], 1, 16, 4, True, 'train'),
+            batch=2, seed=99, with_train=False, scale_weights=0.1)
+    # sr3_uncond: UNCONDITIONAL SR3 (config/sample_sr3_128.json's shape: which_model_G sr3, in_channel 3, conditional
+    # false): sample() starts from noise, snapshots accumulate from x_T, continous=False returns ret_img[-1]
+    # (sr3 diffusion.py:180-187); p_losses feeds x_noisy alone (:238-239)
+    if want('sr3_uncond'):
+      build('sr3_uncond', make_opt('sr3', 3, 8, 4, [1, 2, 2], [8], 1, 16, 8, False, 'train'),
+            batch=2, seed=777, scale_weights=0.1)
+
+
+if __name__ == '__main__':
+    build_all(set(sys.argv[1:]) or None)

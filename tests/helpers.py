@@ -14,13 +14,17 @@ DESCS = {
                       channel_mults=[1, 2], attn_res=[8], res_blocks=2, image_size=16),
     'sr3_seam': dict(variant='sr3', in_channel=6, out_channel=3, inner_channel=32, norm_groups=32,
                      channel_mults=[1, 2], attn_res=[8], res_blocks=1, image_size=16),
+    # unconditional SR3 (the shape of config/sample_sr3_128.json: which_model_G sr3, in_channel 3, conditional false)
+    'sr3_uncond': dict(variant='sr3', in_channel=3, out_channel=3, inner_channel=8, norm_groups=4,
+                       channel_mults=[1, 2, 2], attn_res=[8], res_blocks=1, image_size=16),
 }
 SCHEDS = {
     'sr3_tiny': dict(schedule='linear', n_timestep=8, linear_start=1e-6, linear_end=1e-2),
     'ddpm_tiny': dict(schedule='linear', n_timestep=6, linear_start=1e-4, linear_end=2e-2),
     'sr3_seam': dict(schedule='linear', n_timestep=4, linear_start=1e-6, linear_end=1e-2),
+    'sr3_uncond': dict(schedule='linear', n_timestep=8, linear_start=1e-6, linear_end=1e-2),
 }
-CONDITIONAL = {'sr3_tiny': True, 'ddpm_tiny': False, 'sr3_seam': True}
+CONDITIONAL = {'sr3_tiny': True, 'ddpm_tiny': False, 'sr3_seam': True, 'sr3_uncond': False}
 
 
 def load_golden(name):

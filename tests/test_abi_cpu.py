@@ -40,7 +40,7 @@ def test_plan_error_convention_no_gpu():
         E.Plan('sr3', 6, 3, 8, 4, [1, 2, 2], [8], 1, 18)       # image size not divisible
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_seam'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_seam', 'sr3_uncond'])
 def test_param_table_is_reference_state_dict_schema(name):
     from sr3_hip import engine as E
     d = DESCS[name]
@@ -70,7 +70,7 @@ def test_full_size_plan_matches_survey_counts():
     assert sum(e['numel'] for e in r.table) == 155334339
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_seam'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_seam', 'sr3_uncond'])
 def test_dropin_state_dict_roundtrip(name):
     import model as Model
     m = Model.create_model(opt_for(name, gpu=False))
@@ -158,15 +158,22 @@ def test_plan_launch_list_no_gpu():
     gets, what is fused, and that the opt-in split option only re-targets halo-tile convolutions."""
     from sr3_hip import engine as E
     p = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
-    # default inference plan: every 3x3 stride-1 conv on a map of 16x16 or larger on the Winograd F(2x2,3x3) kernel
-    # (tile 11); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd kernel has no second K-segment)
+    # default inference plan: EVERY 3x3 stride-1 conv on the Winograd F(2x2,3x3) kernel (tile 11; round 4: the 8x8 maps too,
+    # four images per workgroup tile, split-K); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd
+    # kernel has no second K-segment)
     wops = p.op_list(16)
     assert len(wops) == p.num_ops(16) == 168      # (round 3: the input conv writes its own GroupNorm partials: no statistics pass)
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     wconvs = [o for o in wops if o['kind'] == 50]
-    for o in wconvs:      # 8x8 maps keep the direct halo kernel (split-K, so without the fused res_conv segment)
-        assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
+    for o in wconvs:
+        assert (o['tile_cfg'] == 11) == (o['ksize'] == 3 and o['stride'] == 1), o
         assert not o['fused_res_conv_cin']
+        if o['tile_cfg'] == 11 and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
+            assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
+    # a batch that is not a multiple of 4 keeps the direct halo kernel on the 8x8 maps
+    for o in p.op_list(3):
+        if o['kind'] == 50 and o['ksize'] == 3 and o['stride'] == 1:
+            assert (o['tile_cfg'] == 11) == (o['h_out'] >= 16), o
     assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 18
     assert abs(sum(o['flops'] for o in wops) / 16 / 1e9 - 92.18) < 0.05       # algorithmic FLOPs do not change
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) > 0

@@ -179,3 +179,45 @@ def test_bench_refuses_inconsistent_rank_counts():
     r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=dict(env, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0'),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 2 and b'WORLD_SIZE=4' in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-300:])
+
+
+def _valwave_worker(rank, world, port, shapes, ret):
+    sys.path.insert(0, PKG)
+    import torch.distributed as dist
+    from sr3_hip import dist as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    class Net(object):                  # stands in for the reverse loop: result depends on the item and on `continous`
+        calls = []
+
+        def super_resolution(self, cond, continous):
+            Net.calls.append(tuple(cond.shape))
+            img = cond * 3 + 1
+            return torch.cat([cond, img], 0) if continous else img[-1]
+    conds = [torch.arange(1 * 3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k for k, (h, w) in enumerate(shapes)]
+    out = {}
+    for continous in (True, False):
+        wave = D.ValWave(conds)
+        out[continous] = [wave.result(Net(), pos, continous).clone() for pos in range(len(conds))]
+    ret[rank] = (out, Net.calls)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('shapes', [[(4, 4), (8, 6)], [(8, 8)], [(2, 2), (2, 2)]])
+def test_validation_wave_mixed_shapes_and_ragged_wave_two_ranks(shapes):
+    """ValWave (validation / inference items dealt over the ranks): items of DIFFERENT resolutions in one wave and a last
+    wave with fewer items than ranks both come back complete on every rank, each chain run exactly once, on one rank."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_valwave_worker, args=(world, port, shapes, ret), nprocs=world, join=True)
+    for r in range(world):
+        out, calls = ret[r]
+        mine = [(1, 3, h, w) for k, (h, w) in enumerate(shapes) if k == r]
+        assert calls == mine * 2, (r, calls)                 # once per `continous` flavour, own item only
+        for k, (h, w) in enumerate(shapes):
+            cond = torch.arange(3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k
+            assert torch.equal(out[True][k], torch.cat([cond, cond * 3 + 1], 0))
+            assert torch.equal(out[False][k], (cond * 3 + 1)[-1])

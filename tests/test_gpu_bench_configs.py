@@ -6,13 +6,15 @@ CPU oracle on the same seeded inputs:
   C4  SR3 64->512, batch 4: one graph-replayed reverse step;
   C5  DDPM-128, batch 32: UNet forward with per-sample timesteps; training step with dropout 0.2;
   C3  SR3 16->128 training, batch 64, dropout 0.2 (the `train` leg of bench.py): loss and every parameter gradient
-      vs torch autograd over the oracle, evaluated in 8 chunks of 8 images (the gradient of the sum-reduced loss is
-      the sum over chunks; the dropout mask is a function of the element's index in the full batch).
+      vs FLOAT64 torch autograd over the oracle run on cuda, evaluated in 8 chunks of 8 images (the gradient of the
+      sum-reduced loss is the sum over chunks; the dropout mask is a function of the element's index in the full
+      batch); three draws (uniform / all-low / all-high noise levels) x both plans (Winograd, direct).
 
 The plans at these batch sizes pick other kernels than at batch 1 (the Winograd kernel with and without split-K, the
 8-wave 256x128 direct tile, split-K 2/4/8/16 on the small layers, the 8-wave 64x32 dropout form) -- each test asserts
 the plan really contains them, so a heuristic change that silently moves the bench onto untested kernels fails here.
-Tolerances: forward / step 2e-5 * max(1, |ref|_inf); loss rel 1e-5; gradients normwise rel 1e-4."""
+Tolerances: forward / step 2e-5 * max(1, |ref|_inf); loss rel 1e-5; gradients normwise rel 3e-5 against float64
+(SURVEY's 1e-4 was stated against an fp32 reference)."""
 import pytest
 import torch
 
@@ -85,9 +87,9 @@ def test_c2_batch16_forward_and_graph_step():
     B = 16
     netG, sd, desc, opt, c = _build('sr3_16_128')
     cfgs = _cfgs(netG, B)
-    # the bench plan: Winograd F(2x2,3x3) kernel (tile 11) on the 128^2 .. 16^2 layers (split-K 2 at 16^2), the direct
-    # 128x128 halo tile with split-K >= 8 on the 8^2 layers
-    assert (11, 1) in cfgs and (11, 2) in cfgs and any(t == 5 and k >= 8 for t, k in cfgs), sorted(set(cfgs))
+    # the bench plan: Winograd F(2x2,3x3) kernel (tile 11) on every 3x3 stride-1 layer: unsplit at 128^2 .. 32^2, split-K 2 at
+    # 16^2, the four-image tile with split-K 8 on the 8^2 layers (round 4; the direct halo kernel is gone from this plan)
+    assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(5 <= t <= 10 for t, _ in cfgs), sorted(set(cfgs))
     d = G.dev()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 6, 128, 128, generator=g)
@@ -132,57 +134,72 @@ def test_c5_batch32_forward():
     print('C5 batch 32: eps max abs err %.2e (|ref|max %.2f)' % (err, ref.abs().max().item()))
 
 
-def _train_step_vs_chunked_oracle(name, B, chunk, p_drop, seed):
+def _gammas(mode, B, g):
+    u = torch.rand(B, generator=g)
+    if mode == 'uniform':
+        return u * 0.9 + 0.05
+    if mode == 'low':                      # sqrt(alpha_bar) ~ 0.05: x_noisy is almost pure noise
+        return 0.05 + 0.01 * u
+    if mode == 'high':                     # ~ 0.999: x_noisy is almost the clean image
+        return 0.999 + 0.0009 * u
+    raise ValueError(mode)
+
+
+def _train_step_vs_float64(name, B, chunk, p_drop, seed, data_seed=8, gamma_mode='uniform', winograd=1, bound=3e-5):
+    """Loss and every parameter gradient of one engine training step against FLOAT64 autograd over the oracle (run on cuda,
+    chunks of `chunk` images, the engine's dropout mask for the element's position in the full batch), with the noise draw
+    nudged off the kinks of the L1 loss first (tests/grad_ref.py: why, and what that changes -- nothing on the path)."""
     from oracle import sr3_oracle as O
+    import grad_ref as R
     netG, sd, desc, opt, c = _build(name, phase='train', seed=17, dropout=p_drop)
     netG.train()
+    plan = netG.denoise_fn.plan
+    plan.set_option('winograd', winograd)
     d = G.dev()
     S = c['size']
-    g = torch.Generator().manual_seed(8)
+    g = torch.Generator().manual_seed(data_seed)
     hr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
     sr = torch.rand(B, 3, S, S, generator=g) * 2 - 1
     z = torch.randn(B, 3, S, S, generator=g)
-    data = {'HR': hr.to(d), 'SR': sr.to(d)}
     if c['which'] == 'sr3':
-        gamma = torch.rand(B, generator=g) * 0.9 + 0.05
-        loss = netG.p_losses(data, noise=z.to(d), gamma=gamma, drop_seed=seed)
+        gamma = _gammas(gamma_mode, B, g)
+        extra = dict(gamma=gamma, conditional=True)
     else:
         t = torch.randint(0, 2000, (B,), generator=g)
-        tab = O.schedule_tables(opt['model']['beta_schedule']['train'])
+        extra = dict(t=t, tab=O.schedule_tables(opt['model']['beta_schedule']['train']), conditional=False)
+    z, moved, rmin = R.dekink(O, sd, desc, c['which'], hr, sr, z, extra, p_drop, seed, chunk)
+    data = {'HR': hr.to(d), 'SR': sr.to(d)}
+    if c['which'] == 'sr3':
+        loss = netG.p_losses(data, noise=z.to(d), gamma=gamma, drop_seed=seed)
+    else:
         loss = netG.p_losses(data, noise=z.to(d), t=t.to(d), drop_seed=seed)
     torch.cuda.synchronize()
     got_loss = float(loss)
-    grads = {k: v.cpu().clone() for k, v in netG.denoise_fn.named_gradients()}
-    # dropout convs of the train plan: none may sit on a tile without a tested dropout instantiation
-    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
-    ref_loss = 0.0
-    for lo in range(0, B, chunk):
-        sl = slice(lo, lo + chunk)
-        drop = (p_drop, seed, lo) if p_drop > 0 else None
-        if c['which'] == 'sr3':
-            l = O.p_losses_sr3(sdr, desc, hr[sl], sr[sl], gamma[sl], z[sl], conditional=True, dropout=drop)
-        else:
-            l = O.p_losses_ddpm(sdr, desc, tab, hr[sl], sr[sl], t[sl], z[sl], conditional=False, dropout=drop)
-        (l / hr.numel()).backward()              # 1 / (GLOBAL b c h w), model/model.py:52-53
-        ref_loss += float(l.detach())
+    grads = {k: v.detach().clone() for k, v in netG.denoise_fn.named_gradients()}
+    kinds = set(cfg for cfg, _ in [(o['tile_cfg'], o['ksplit']) for o in plan.op_list(B)])
+    assert (11 in kinds) == bool(winograd), kinds               # the plan really is the one this case is named after
+    ref, ref_loss, dt = R.oracle_grads(O, sd, desc, c['which'], hr, sr, z, extra, p_drop, seed, chunk)
     assert abs(got_loss - ref_loss) <= 1e-5 * abs(ref_loss), (got_loss, ref_loss)
-    worst = []
-    for key, grad in grads.items():
-        ref = sdr['denoise_fn.' + key].grad
-        num, den = (grad - ref).norm().item(), max(ref.norm().item(), 1e-12)
-        worst.append((num / den, key, den))
-    worst.sort(reverse=True)
-    bad = [w for w in worst if w[0] > 1e-4 and w[2] > 1e-7]
-    assert len(worst) > 150 and not bad, bad[:8]
-    print('%s training step, batch %d, dropout %.1f: loss rel err %.1e, worst gradient rel err %.1e (%s) over %d tensors'
-          % (name, B, p_drop, abs(got_loss - ref_loss) / abs(ref_loss), worst[0][0], worst[0][1], len(worst)))
+    rows = R.rel_errors(grads, ref)
+    bad = [w for w in rows if w[0] > bound and w[2] > 1e-7]
+    print('%s training step, batch %d, dropout %.1f, gamma %s, data seed %d, winograd=%d: loss rel err %.1e, worst gradient rel '
+          'err vs float64 %.1e (%s), median %.1e over %d tensors; %d of %d noise elements moved off the L1 kinks (min |eps - z| '
+          '%.1e); float64 reference %.0f s' % (name, B, p_drop, gamma_mode, data_seed, winograd,
+                                              abs(got_loss - ref_loss) / abs(ref_loss), rows[0][0], rows[0][1],
+                                              rows[len(rows) // 2][0], len(rows), moved, z.numel(), rmin, dt))
+    assert len(rows) > 150 and not bad, bad[:8]
 
 
-def test_c3_train_batch64_dropout():
-    """The `train` leg of bench.py: SR3 16->128, 64 images per GPU, dropout 0.2."""
-    _train_step_vs_chunked_oracle('sr3_16_128', 64, 8, 0.2, 20240607)
+# 3 draws x both plans (VERDICT r3 #1): the seeded uniform batch of rounds 2-3, a batch of almost pure noise (gamma ~ 0.05) and
+# a batch of almost clean images (gamma ~ 0.999); `winograd = 0` is a supported plan option and what `split_bf16` falls back to
+@pytest.mark.parametrize('winograd', [1, 0])
+@pytest.mark.parametrize('data_seed,gamma_mode', [(8, 'uniform'), (10, 'low'), (9, 'high')])
+def test_c3_train_batch64_dropout(data_seed, gamma_mode, winograd):
+    """The `train` leg of bench.py: SR3 16->128, 64 images per GPU, dropout 0.2.  Stated bound for the gradients: 3e-5
+    normwise against float64 (measured 5e-7, what stock PyTorch-ROCm fp32 gives on the same batch: 3e-7)."""
+    _train_step_vs_float64('sr3_16_128', 64, 8, 0.2, 20240607, data_seed, gamma_mode, winograd)
 
 
 def test_c5_train_batch32_dropout():
     """BASELINE.json configs[4]: DDPM-128 training, 32 images per GPU, dropout 0.2 (config/sample_ddpm_128.json)."""
-    _train_step_vs_chunked_oracle('ddpm_128', 32, 8, 0.2, 77001)
+    _train_step_vs_float64('ddpm_128', 32, 8, 0.2, 77001)

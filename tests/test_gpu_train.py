@@ -20,7 +20,7 @@ def build_train(name):
     return m, g, sd
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_uncond'])
 def test_loss_and_gradients_match_reference_autograd(name):
     m, g, sd = build_train(name)
     d = G.dev()
@@ -46,7 +46,7 @@ def test_loss_and_gradients_match_reference_autograd(name):
     assert not bad, 'gradient mismatch (rel err, key, |ref|): %s' % bad[:8]
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_uncond'])
 def test_optimize_parameters_one_adam_step(name):
     """feed_data -> optimize_parameters (RNG draws patched to the recorded ones) -> weights after Adam."""
     m, g, sd = build_train(name)

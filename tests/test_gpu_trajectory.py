@@ -1,11 +1,13 @@
 """Full-trajectory parity at the benchmarked sizes: the metric is a 2000-step sample (reference
 model/sr3_modules/diffusion.py:176-200, model/ddpm_modules/diffusion.py:200-230), so the PRODUCTION hipGraph is replayed
-for all 2000 reverse steps at the BASELINE.json batch (C2: SR3 16->128, batch 16; C5: DDPM-128, batch 32) with the z it
+for all 2000 reverse steps at the BASELINE.json batch (C2: SR3 16->128, batch 16; C4: SR3 64->512, batch 4; C5: DDPM-128,
+batch 32) with the z it
 draws in-graph recorded step by step, and compared with
 
   (a) the oracle's own ops (oracle/sr3_oracle.py, functional restatement of the reference) run on `cuda` through stock
       PyTorch-ROCm, fed the same x_T, conditioning and z -- the whole batch, all 2000 steps, drift curve printed;
-  (b) the CPU oracle on the last 100 steps for 2 images, started from the engine's own state at step 100.
+  (b) the CPU oracle on the last 100 steps for 2 images, started from the engine's own state at step 100 (C4: the last 10
+      steps of one 512 x 512 image -- a CPU forward of that network is 1.2 TFLOP).
 
 Stated tolerance: full loop <= 1e-4 max abs.  The Winograd arithmetic is on this path; what is measured
 here is its accumulated drift over the whole chain, not one step."""
@@ -23,7 +25,7 @@ T_STEPS = 2000
 TAIL = 100
 
 
-def _trajectory(name, B, tail_images=2):
+def _trajectory(name, B, tail_images=2, TAIL=TAIL):
     from oracle import sr3_oracle as O
     netG, sd, desc, opt, c = _build(name)
     d = G.dev()
@@ -99,3 +101,9 @@ def test_c2_sr3_16_128_batch16_full_2000_step_trajectory():
 @pytest.mark.timeout(1200)
 def test_c5_ddpm_128_batch32_full_2000_step_trajectory():
     _trajectory('ddpm_128', 32)
+
+
+@pytest.mark.timeout(1800)
+def test_c4_sr3_64_512_batch4_full_2000_step_trajectory():
+    """BASELINE.json configs[3]: the large-activation network (K up to 18432, N = 1024 / d = 1024 mid attention, 16 groups)."""
+    _trajectory('sr3_64_512', 4, tail_images=1, TAIL=10)

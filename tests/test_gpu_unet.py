@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from helpers import DESCS, SCHEDS, CONDITIONAL, load_golden, opt_for      # noqa: E402
 import gpu_util as G                                                     # noqa: E402
 
-NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam']
+NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam', 'sr3_uncond']
 
 
 def build(name, **plan_opts):
@@ -149,7 +149,7 @@ def test_reverse_loop_injected_noise(name):
         G.assert_close(r.cpu(), ref, tol=1e-4, what='%s loop cont=%s' % (name, cont))
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_uncond'])
 def test_graph_replay_equals_eager(name):
     """hipGraph replay of the step (device-side counter, in-graph RNG) == the eager loop, same seed."""
     m, g, sd = build(name)
@@ -180,6 +180,36 @@ def test_api_surface_test_and_visuals():
     assert set(vis.keys()) == {'SR', 'INF', 'HR', 'LR'} and vis['SR'].device.type == 'cpu'
     m.test(continous=False)
     assert tuple(m.SR.shape) == (3, 16, 16)       # ret_img[-1]: last image of the batch only
+
+
+def test_unconditional_sr3_sample_and_visuals():
+    """config/sample_sr3_128.json's case (which_model_G sr3, conditional false) through DDPM.sample, as sample.py:104,140
+    calls it: the snapshots start from x_T, `continous=False` returns ret_img[-1] -- the LAST image of the batch only,
+    (3, H, W) (sr3 diffusion.py:180-187) -- and get_current_visuals(sample=True) returns {'SAM'}."""
+    m, g, sd = build('sr3_uncond')
+    d = G.dev()
+    T = int(g['meta/T'])
+    n_snap = sum(1 for i in range(T) if i % (1 | (T // 10)) == 0)
+    x_T = torch.from_numpy(g['loop/x_T']).to(d)
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    full = m.netG.p_sample_loop(tuple(x_T.shape), continous=True, x_T=x_T, noise_seq=zs)
+    ref = torch.from_numpy(g['loop/ret_continous'])
+    assert tuple(full.shape) == tuple(ref.shape) == (2 * (n_snap + 1), 3, 16, 16)
+    assert torch.equal(full[:2].cpu(), torch.from_numpy(g['loop/x_T']))          # ret_img starts as x_T itself
+    G.assert_close(full.cpu(), ref, tol=1e-4, what='unconditional sr3 loop')
+    last = m.netG.p_sample_loop(tuple(x_T.shape), continous=False, x_T=x_T, noise_seq=zs)
+    assert tuple(last.shape) == (3, 16, 16)
+    G.assert_close(last.cpu(), torch.from_numpy(g['loop/ret_last']), tol=1e-4, what='unconditional sr3 ret_img[-1]')
+    assert torch.equal(last, full[-1])
+    # the wrapper: DDPM.sample(batch_size, continous) -> self.SR, visuals under 'SAM' (model/model.py:68-78, 98-110)
+    torch.manual_seed(5)
+    m.sample(batch_size=2, continous=True)
+    assert tuple(m.SR.shape) == (2 * (n_snap + 1), 3, 16, 16)
+    vis = m.get_current_visuals(sample=True)
+    assert set(vis.keys()) == {'SAM'} and vis['SAM'].device.type == 'cpu' and tuple(vis['SAM'].shape) == tuple(m.SR.shape)
+    torch.manual_seed(5)
+    m.sample(batch_size=2, continous=False)
+    assert tuple(m.SR.shape) == (3, 16, 16) and torch.equal(m.SR.cpu(), vis['SAM'][-1])
 
 
 def test_engine_refuses_cpu():

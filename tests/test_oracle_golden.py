@@ -7,7 +7,7 @@ import torch
 from oracle import sr3_oracle as O
 from helpers import DESCS, SCHEDS, CONDITIONAL, load_golden
 
-NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam']
+NAMES = ['sr3_tiny', 'ddpm_tiny', 'sr3_seam', 'sr3_uncond']
 TOL = 2e-6     # same torch CPU ops in a different call order; observed ~1e-7
 
 
@@ -88,7 +88,7 @@ def test_p_sample_without_clipping(name):
             assert np.abs(clipped.numpy() - n['%s/mean/%d' % (name, t)]).max() > 1e-3       # the switch matters here
 
 
-@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_uncond'])
 def test_p_losses(name):
     g, sd = load_golden(name)
     d = DESCS[name]; tab = O.schedule_tables(SCHEDS[name]); cond = CONDITIONAL[name]

@@ -8,7 +8,7 @@ normwise relative error of each parameter gradient against that reference; `--f3
 cuda (stock PyTorch-ROCm / MIOpen) and `--f32-cpu` on the host (oneDNN) as the "reference's own fp32 noise" columns.
 
   python tools/grad_probe.py --batch 64 --gamma uniform --data-seed 8 \
-      --variant default --variant winograd=0 --variant dgrad_ksplit=4,dgrad_dbl=1
+      --variant default --variant winograd=0 --kink-margin 1e-4
 """
 import argparse
 import os
@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinem
     sys.path.insert(0, p)
 import torch                                      # noqa: E402
 
-DEFAULTS = dict(winograd=1, ksplit=0, dgrad_ksplit=0, dgrad_dbl=0, fuse_stats=1, fuse_res=1, tile_cfg=0)
+DEFAULTS = dict(winograd=1, ksplit=0, fuse_stats=1, fuse_res=1, tile_cfg=0)
 
 
 def gammas(mode, B, g):
@@ -41,31 +41,13 @@ def gammas(mode, B, g):
 
 
 def oracle_grads(O, sd, desc, hr, sr, gamma, z, p_drop, seed, chunk, dtype, device):
-    t0 = time.time()
-    sdr = {k: (v.to(device=device, dtype=dtype) if v.is_floating_point() else v.to(device)).clone()
-           .requires_grad_(v.is_floating_point() and k.startswith('denoise_fn.')) for k, v in sd.items()}
-    B = hr.shape[0]
-    tot = 0.0
-    for lo in range(0, B, chunk):
-        sl = slice(lo, lo + chunk)
-        drop = (p_drop, seed, lo) if p_drop > 0 else None
-        f = lambda t: t[sl].to(device=device, dtype=dtype)
-        l = O.p_losses_sr3(sdr, desc, f(hr), f(sr), f(gamma), f(z), conditional=True, dropout=drop)
-        (l / hr.numel()).backward()
-        tot += float(l.detach())
-    if device != 'cpu':
-        torch.cuda.synchronize()
-    grads = {k[len('denoise_fn.'):]: v.grad.detach().to('cuda', torch.float64) for k, v in sdr.items() if v.grad is not None}
-    return grads, tot, time.time() - t0
+    import grad_ref as R
+    return R.oracle_grads(O, sd, desc, 'sr3', hr, sr, z, dict(gamma=gamma, conditional=True), p_drop, seed, chunk, dtype, device)
 
 
 def rel_errors(got, ref):
-    rows = []
-    for k, r in ref.items():
-        den = max(r.norm().item(), 1e-30)
-        rows.append(((got[k].double() - r).norm().item() / den, k))
-    rows.sort(reverse=True)
-    return rows
+    import grad_ref as R
+    return [(e, k) for e, k, _ in R.rel_errors(got, ref)]
 
 
 def main():
@@ -80,6 +62,8 @@ def main():
     ap.add_argument('--f32-cpu', action='store_true')
     ap.add_argument('--ref-device', default='cuda')
     ap.add_argument('--variant', action='append', default=[])
+    ap.add_argument('--kink-margin', type=float, default=0.0,
+                    help='> 0: nudge z away from the kinks of the L1 loss first (tests/grad_ref.py:dekink)')
     ap.add_argument('--ref-cache', default=None, help='file to keep the float64 reference gradients in between runs')
     a = ap.parse_args()
     from oracle import sr3_oracle as O
@@ -94,6 +78,13 @@ def main():
     z = torch.randn(B, 3, S, S, generator=g)
     gamma = gammas(a.gamma, B, g)
     print('batch %d, data seed %d, gamma mode %s: min %.4f max %.4f' % (B, a.data_seed, a.gamma, gamma.min(), gamma.max()), flush=True)
+    if a.kink_margin > 0:
+        import grad_ref as R
+        t0 = time.time()
+        z, moved, rmin = R.dekink(O, sd, desc, 'sr3', hr, sr, z, dict(gamma=gamma, conditional=True), a.dropout, seed, a.chunk,
+                                  a.kink_margin)
+        print('de-kinked z: %d of %d elements moved by %.0e, min |eps - z| now %.2e (%.0f s)'
+              % (moved, z.numel(), 4 * a.kink_margin, rmin, time.time() - t0), flush=True)
     plan = netG.denoise_fn.plan
     eng = {}
     for var in (a.variant or ['default']):
