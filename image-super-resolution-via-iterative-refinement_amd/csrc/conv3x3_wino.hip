@@ -42,6 +42,7 @@
 namespace sr3 {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int WBN = 64;         // output channels per workgroup
@@ -89,6 +90,20 @@ __device__ __forceinline__ float silu_w(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 #endif
 }
+// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits, each residual exact in fp32) for the eight values a lane
+// contributes to one v_mfma_f32_32x32x16_bf16 operand
+__device__ __forceinline__ void split3x8(const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = e < 4 ? lo[e] : hi[e - 4];
+    const __bf16 hh = (__bf16)v;
+    const float r1 = v - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+  }
+}
+constexpr int WUS = 3 * 64 * 8;          // SPLIT: bf16 elements of one (position, n block) fragment group: 3 planes x 64 lanes x 8
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -141,14 +156,79 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
   }
 }
 
-size_t wino_weight_floats(int Cout, int Cin) {
-  const size_t ncb = (Cout + WBN - 1) / WBN, nch = (Cin + WCK - 1) / WCK;
-  return ncb * nch * 16 * 1024;
+// The same filters for the SPLIT kernel: every U value as three bf16 terms, laid out as the B operand of
+// v_mfma_f32_32x32x16_bf16 (one MFMA = a whole 16-channel chunk):
+//   ufrag_s[cout_blk][chunk][pos][nblk 2][plane 3 (h, m, l)][lane 64][8 bf16]
+//   lane l holds U_pos[n = cout_blk*64 + nblk*32 + (l & 31)] for the 8 channels k = 0..7 of its half hq = l >> 5:
+//   channel = chunk*16 + (k < 4 ? 4 hq + k : 8 + 4 hq + (k - 4))  -- the order in which the kernel's transform lanes hold
+//   their channels (quad hq of either half chunk), so V needs no shuffle.  One thread per (n, chunk, hq).
+__global__ __launch_bounds__(256) void k_wino_weights_split(const float* __restrict__ w, int Cout, int Cin, int nchunks,
+                                                             int ncb, __bf16* __restrict__ ufrag) {
+  const long total = (long)ncb * WBN * nchunks * 2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int hq = (int)(idx & 1);
+    const int chunk = (int)((idx >> 1) % nchunks);
+    const int n = (int)((idx >> 1) / nchunks);
+    f32x4 uu[2][16];                                  // [half chunk][position]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int c = chunk * WCK + hf * 8 + hq * 4;
+      f32x4 g[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n < Cout && c < Cin) g[t] = *reinterpret_cast<const f32x4*>(w + ((size_t)n * 9 + t) * Cin + c);
+      }
+      f32x4 gg[4][3];
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const f32x4 g0 = g[0 * 3 + s_], g1 = g[1 * 3 + s_], g2 = g[2 * 3 + s_];
+        gg[0][s_] = g0;
+        gg[1][s_] = (g0 + g1 + g2) * 0.5f;
+        gg[2][s_] = (g0 - g1 + g2) * 0.5f;
+        gg[3][s_] = g2;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uu[hf][i * 4 + 0] = gg[i][0];
+        uu[hf][i * 4 + 1] = (gg[i][0] + gg[i][1] + gg[i][2]) * 0.5f;
+        uu[hf][i * 4 + 2] = (gg[i][0] - gg[i][1] + gg[i][2]) * 0.5f;
+        uu[hf][i * 4 + 3] = gg[i][2];
+      }
+    }
+    const int cb = n / WBN, nl = n - cb * WBN;
+    const int nblk = nl >> 5;
+    const int lane = (nl & 31) + 32 * hq;
+    __bf16* base = ufrag + ((size_t)(cb * nchunks + chunk) * 16) * (2 * WUS) + (size_t)nblk * WUS + lane * 8;
+#pragma unroll
+    for (int pos = 0; pos < 16; ++pos) {
+      bf16x8 h, m, l;
+      split3x8(uu[0][pos], uu[1][pos], h, m, l);
+      __bf16* q = base + (size_t)pos * (2 * WUS);
+      *reinterpret_cast<bf16x8*>(q) = h;
+      *reinterpret_cast<bf16x8*>(q + 512) = m;
+      *reinterpret_cast<bf16x8*>(q + 1024) = l;
+    }
+  }
 }
 
-int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st) {
+size_t wino_weight_floats(int Cout, int Cin, bool split) {
+  const size_t ncb = (Cout + WBN - 1) / WBN, nch = (Cin + WCK - 1) / WCK;
+  return ncb * nch * 16 * (split ? (size_t)WUS : 1024);     // (split: 2 x WUS bf16 = WUS floats per position)
+}
+
+int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st, bool split) {
   if ((Cin & 3) != 0) { set_error("wino: Cin %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   const int ncb = (Cout + WBN - 1) / WBN, nch = (Cin + WCK - 1) / WCK;
+  if (split) {
+    const long total = (long)ncb * WBN * nch * 2;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_wino_weights_split, dim3(blocks), dim3(256), 0, st, w_ohwi, Cout, Cin, nch, ncb,
+                       reinterpret_cast<__bf16*>(ufrag));
+    SR3_LAUNCH_CHECK("k_wino_weights_split");
+    return SR3_OK;
+  }
   const long total = (long)ncb * WBN * nch * 4;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
@@ -174,7 +254,11 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 // DROP: train-mode dropout between the activation and the conv (nn.Dropout of Block, unet.py:86): the staged element with NHWC
 // index i of the (single, non-upsampled) source is kept iff hash32(i * 0x9E3779B9 + seed) >= thresh and scaled by 1 / (1 - p),
 // exactly as conv3x3_halo.hip does -- the mask applies to the activated input BEFORE the transform, so it fits the staging step.
-template <int DBG, bool DROP, bool NB4>
+// SPLIT: every fp32 operand as three bf16 terms (x = h + m + l) and each product as the six bf16 MFMA products
+// hh + hm + mh + mm + hl + lh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped terms are <= 2^-24 of a product
+// (fp32-class results, conv3x3_halo.hip's MODE 1 applied to the Winograd domain): U comes pre-split from the derived buffer
+// (k_wino_weights_split), V is split in registers right after the transform.  Plan option `wino_split`; gated by tests.
+template <int DBG, bool DROP, bool NB4, bool SPLIT>
 __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, const WinoGeom g,
                                                          const float* __restrict__ ufrag) {
   using GE = WGeo<NB4>;
@@ -229,31 +313,35 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // ---- raw staging items of this thread: item j covers halo pixel (tid >> 2) + 128 j, channel quad tid & 3 ----
   // hinfo packs what is tile-independent: LDS float offset (bits 0..15), halo row (16..23), halo column (24..31); -1: no item
   const int kq = tid & 3, lrow = tid >> 2;
-  int hinfo[WHI], hpix[WHI];
+  int hinfo_r[WHI], hpix[WHI];
+  auto hinfo_of = [&](int j, int t_) {
+    const int hp = (t_ >> 2) + (WNT / 4) * j;
+    const int hy = hp / TWp, hx = hp - hy * TWp;
+    return hp < WHP ? (hy * WROW + ((hy >> 1) & 1) * GE::SHIFT + hx * WRS) | (hy << 16) | (hx << 24) : -1;
+  };
 #pragma unroll
   for (int j = 0; j < WHI; ++j) {
-    const int hp = lrow + (WNT / 4) * j;
-    hinfo[j] = -1;
+    hinfo_r[j] = hinfo_of(j, tid);
     hpix[j] = -1;
-    if (hp < WHP) {
-      const int hy = hp / TWp, hx = hp - hy * TWp;
-      hinfo[j] = (hy * WROW + ((hy >> 1) & 1) * GE::SHIFT + hx * WRS) | (hy << 16) | (hx << 24);
-    }
   }
-  auto set_pixels = [&]() {                       // source pixel of every staging item of the current tile (-1: zero padding)
-#pragma unroll
-    for (int j = 0; j < WHI; ++j) {
-      int hy = (hinfo[j] >> 16) & 0xff, hx = (hinfo[j] >> 24) & 0xff;
-      int bi = b0;
-      if (NB4) {                                    // halo block (hy / 10, hx / 10) of the 2 x 2 image grid
-        const int iy = hy >= 10 ? 1 : 0, ix = hx >= 10 ? 1 : 0;
-        bi += iy * 2 + ix; hy -= 10 * iy; hx -= 10 * ix;
-      }
-      const int ih = h0 + hy - 1, iw = w0 + hx - 1;
-      const bool ok = hinfo[j] >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-      hpix[j] = ok ? (bi * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
+  auto hinfo = [&](int j) { return hinfo_r[j]; };
+  auto pixel_of = [&](int j) {                    // source pixel of staging item j of the current tile (-1: zero padding)
+    const int hj = hinfo(j);
+    int hy = (hj >> 16) & 0xff, hx = (hj >> 24) & 0xff;
+    int bi = b0;
+    if (NB4) {                                      // halo block (hy / 10, hx / 10) of the 2 x 2 image grid
+      const int iy = hy >= 10 ? 1 : 0, ix = hx >= 10 ? 1 : 0;
+      bi += iy * 2 + ix; hy -= 10 * iy; hx -= 10 * ix;
     }
+    const int ih = h0 + hy - 1, iw = w0 + hx - 1;
+    const bool ok = hj >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    return ok ? (bi * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
   };
+  auto set_pixels = [&]() {
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) hpix[j] = pixel_of(j);
+  };
+  auto hpx = [&](int j) { return hpix[j]; };
   f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
   f32x4 rh2[WHI];           // ... of the tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
   auto load_raw = [&](int chunk, f32x4 (&r)[WHI]) {
@@ -265,7 +353,8 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     const int cs = second ? ce - p.C0 : ce;
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
-      const int off = hpix[j] >= 0 ? hpix[j] * sC + cs : 0;
+      const int hp_ = hpx(j);
+      const int off = hp_ >= 0 ? hp_ * sC + cs : 0;
       r[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
     }
   };
@@ -287,7 +376,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       if (lrow + (WNT / 4) * j < WHP) {
         f32x4 v = r[j];
         if (NB4 && p.act != 0) {                    // the pairs of THIS item's image: [image][chunk of the split][16 x 2]
-          const int hi_ = hinfo[j];
+          const int hi_ = hinfo(j);
           const int img = (((hi_ >> 16) & 0xff) >= 10 ? 2 : 0) + (((hi_ >> 24) & 0xff) >= 10 ? 1 : 0);
           const float* q = cs_ + 64 + (img * nck + (chunk - c_begin)) * (2 * WCK) + kq * 8;
           ssa = *reinterpret_cast<const f32x4*>(q);
@@ -300,15 +389,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           v.w = fmaf(v.w, ssb.z, ssb.w);
           if (p.act == 2) { v.x = silu_w(v.x); v.y = silu_w(v.y); v.z = silu_w(v.z); v.w = silu_w(v.w); }
           if (DROP) {                                       // single source, no upsampling (host): linear NHWC index
-            const unsigned i0 = (unsigned)(hpix[j] * p.C0 + chunk * WCK + kq * 4);
+            const unsigned i0 = (unsigned)(hpx(j) * p.C0 + chunk * WCK + kq * 4);
             v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
             v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
             v.z *= drop_mask(p.drop_seed, i0 + 2, p.drop_thresh, p.drop_scale);
             v.w *= drop_mask(p.drop_seed, i0 + 3, p.drop_thresh, p.drop_scale);
           }
         }
-        v = (hvalid && hpix[j] >= 0) ? v : zero;
-        int hi = hinfo[j];
+        v = (hvalid && hpx(j) >= 0) ? v : zero;
+        int hi = hinfo(j);
         asm volatile("" : "+v"(hi));                // (the LDS address is derived here, not kept in a register of its own)
         *reinterpret_cast<f32x4*>(&raw[(hi & 0xffff) + kq * 4]) = v;
       }
@@ -411,7 +500,29 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       for (int n = 0; n < 2; ++n) u[pj][n][kk] = *reinterpret_cast<const f32x4*>(q + pj * 1024 + (n * 2 + kk) * 256);
   };
 
+  // SPLIT: [pj][nblk][plane] bf16x8, one whole chunk per fragment; single-buffered, re-filled group by group (pj) right after
+  // the group's last MFMA of the chunk
+  bf16x8 us[2][2][3];
+  const __bf16* ubase_s = nullptr;
+  auto load_us = [&](int chunk, int pj) {
+    const __bf16* q = ubase_s + (size_t)chunk * 16 * (2 * WUS) + pj * (2 * WUS);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) us[pj][n][pl] = *reinterpret_cast<const bf16x8*>(q + n * WUS + pl * 512);
+  };
+
   f32x16 acc[2][2][2];          // [pj][mblk][nblk]
+  // SPLIT: the 12 MFMAs of one position (pj) of tile block m: product-major over the two n blocks (two independent
+  // accumulators between dependent MFMAs), smallest terms first
+  auto mfma_split = [&](int m, int pj, const bf16x8 (&v)[3]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[PA[q]], us[pj][n][PB[q]], acc[pj][m][n], 0, 0, 0);
+  };
   auto mfma_unit = [&](int m, int kk, const f32x4& va, const f32x4& vb) {   // 16 MFMAs: tile block m, channels 8 kk .. 8 kk + 7
     if (DBG & 1) {               // keep the operands live, issue no MFMA
 #pragma unroll
@@ -465,9 +576,15 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       int l_ = lane;
       asm volatile("" : "+v"(l_));
       ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + l_ * 4;
+      ubase_s = reinterpret_cast<const __bf16*>(ufrag) + (size_t)cb * nch * 16 * (2 * WUS) + (size_t)(wi * 4 + wh * 2) * (2 * WUS) + l_ * 8;
     }
-    load_u(c_begin, 0);                               // L2 hits (every tile of the cout block reads them): back before the
-    load_u(c_begin, 1);                               // two staging steps below are done
+    if (SPLIT) {
+      load_us(c_begin, 0);
+      load_us(c_begin, 1);
+    } else {
+      load_u(c_begin, 0);                             // L2 hits (every tile of the cout block reads them): back before the
+      load_u(c_begin, 1);                             // two staging steps below are done
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -491,7 +608,76 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     //   reads (m1,kk1)  | MFMA (m0,kk1) | finish (m1,kk1)
     //   barrier: raw[i & 1] is fully consumed -> stage chunk i + 2 into it; chunk i + 1's tile is visible
     //   reads (m0,kk0) of chunk i + 1 | MFMA (m1,kk1) | finish    U fragments kk1 of chunk i + 1
-    {
+    if constexpr (SPLIT) {
+      // Units are whole tile blocks (m) of a chunk: K = 16 is one bf16 MFMA.  Per unit: the transform of the NEXT unit in two
+      // halves (the six LDS reads of half chunk kk = 0 before the first MFMA group, those of kk = 1 before the second -- 24
+      // registers in flight instead of 48), its 3 x bf16 split after the second group; the U fragments of the next chunk are
+      // fetched per position right after that position's last MFMA of the chunk (one buffer, >= 1 k cycles ahead of use).
+      //   reads kk0 (m1)       | MFMA (m0, pos a) x 12 | finish kk0 ; reads kk1 (m1)
+      //                        | MFMA (m0, pos b) x 12 | finish kk1 ; split -> V (m1)
+      //   barrier ; stage chunk i + 2 ; reads kk0 (m0 of chunk i + 1)
+      //                        | MFMA (m1, pos a) x 12 | U pos a of chunk i + 1 ; finish kk0 ; reads kk1
+      //                        | MFMA (m1, pos b) x 12 | U pos b of chunk i + 1 ; finish kk1 ; split -> V (m0, i + 1)
+      bf16x8 vsa[3], vsb[3];
+      f32x4 va0, vb0, va1, vb1;
+      {
+        f32x4 da[3], db[3];
+        t_load(raw0, 0, 0, da, db);
+        t_finish(da, db, va0, vb0);
+        t_load(raw0, 0, 1, da, db);
+        t_finish(da, db, va1, vb1);
+        split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+      }
+      // (position b stays in fp32 -- wb0, wb1 -- until its own MFMA group: 8 registers instead of 12 across group a.  No LDS read
+      // is in flight across an MFMA group -- this instantiation has no registers for that: the six reads of a half-unit are
+      // issued right behind a group, with the other position's split between them and their use where there is one; the
+      // partner wave of the SIMD owns the matrix pipe meanwhile)
+      f32x4 wb0 = vb0, wb1 = vb1;
+      for (int i = 0; i < nck; ++i) {
+        float* rcur = (i & 1) ? raw1 : raw0;
+        const float* rnext = (i & 1) ? raw0 : raw1;
+        const bool more = i + 1 < nck;
+        f32x4 da[3], db[3];
+        mfma_split(0, 0, vsa);
+        __builtin_amdgcn_sched_barrier(0);
+        split3x8(wb0, wb1, vsb[0], vsb[1], vsb[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        t_load(rcur, 1, 0, da, db);
+        t_finish(da, db, va0, vb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split(0, 1, vsb);
+        __builtin_amdgcn_sched_barrier(0);
+        t_load(rcur, 1, 1, da, db);
+        t_finish(da, db, va1, vb1);
+        split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+        wb0 = vb0; wb1 = vb1;
+        __syncthreads();
+        if (i + 2 < nck) {
+          store_raw(rcur, c_begin + i + 2, rh, cs_);
+          if (i + 3 < nck) load_raw(c_begin + i + 3, rh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split(1, 0, vsa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_us(c_begin + i + 1, 0);
+        split3x8(wb0, wb1, vsb[0], vsb[1], vsb[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          t_load(rnext, 0, 0, da, db);
+          t_finish(da, db, va0, vb0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_split(1, 1, vsb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+          load_us(c_begin + i + 1, 1);
+          t_load(rnext, 0, 1, da, db);
+          t_finish(da, db, va1, vb1);
+          split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+          wb0 = vb0; wb1 = vb1;
+        }
+      }
+    } else {
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       {
         f32x4 da[3], db[3];
@@ -772,21 +958,27 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const char* np = getenv("SR3_WINO_NONPERSISTENT");
   dim3 grid((unsigned)((np && np[0] == '1') ? ntiles : std::min<long>(ntiles, n_cu > 0 ? n_cu : 256)), p.ksplit);
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
-#define SR3_WINO_LAUNCH3(D, DR, N4)                                                                                   \
+#define SR3_WINO_LAUNCH4(D, DR, N4, SP)                                                                               \
   {                                                                                                                   \
     static std::atomic<uint64_t> done{0};                                                                             \
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D, DR, N4>), W_SMEM, done)) return rc;   \
-    hipLaunchKernelGGL((k_conv3x3_wino<D, DR, N4>), grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                        \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino<D, DR, N4, SP>), W_SMEM, done)) return rc; \
+    hipLaunchKernelGGL((k_conv3x3_wino<D, DR, N4, SP>), grid, dim3(WNT), W_SMEM, st, p, g, ufrag);                    \
   }
+#define SR3_WINO_LAUNCH3(D, DR, N4) SR3_WINO_LAUNCH4(D, DR, N4, false)
 #define SR3_WINO_LAUNCH2(D, DR)                                                                                       \
   if (g.NB == 1) SR3_WINO_LAUNCH3(D, DR, false) else SR3_WINO_LAUNCH3(D, DR, true)
 #define SR3_WINO_LAUNCH(D)                                                                                            \
   if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
+  if (p.wino_split && (p.drop_thresh != 0 || dbg != 0 || g.NB != 1)) {
+    set_error("conv: the split-bf16 Winograd kernel covers the one-image tile without dropout only");
+    return SR3_E_UNSUPPORTED;
+  }
   switch (dbg) {
     case 0:
-      if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
+      if (p.wino_split) { SR3_WINO_LAUNCH4(0, false, false, true) }
+      else if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
       break;
 #ifdef SR3_WINO_ABLATIONS
     case 1: { SR3_WINO_LAUNCH(1) } break;
@@ -805,6 +997,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
 #undef SR3_WINO_LAUNCH
 #undef SR3_WINO_LAUNCH2
 #undef SR3_WINO_LAUNCH3
+#undef SR3_WINO_LAUNCH4
   SR3_LAUNCH_CHECK("k_conv3x3_wino");
   return SR3_OK;
 }

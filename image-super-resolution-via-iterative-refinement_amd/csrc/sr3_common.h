@@ -110,6 +110,7 @@ struct ConvParams {
   float drop_scale;
   // tile_cfg 11 (Winograd): this conv's transformed filters in fragment-major order (conv3x3_wino.hip)
   const float* wino_u;
+  int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI)
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -165,8 +166,8 @@ int wino_stats_slices(const WinoGeom& g);
 int wino_max_chunks_per_split(const WinoGeom& g);     // 64 (1024 input channels); 16 for the four-image tile
 long wino_workgroups(const ConvParams& p, const WinoGeom& g);
 int wino_chunks(const ConvParams& p);
-size_t wino_weight_floats(int Cout, int Cin);
-int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st);
+size_t wino_weight_floats(int Cout, int Cin, bool split = false);
+int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st, bool split = false);
 int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------

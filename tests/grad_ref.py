@@ -40,7 +40,7 @@ def _sr3_loss(O, sdd, desc, hr, sr, sl, z, drop, extra, residual=False):
 def _ddpm_loss(O, sdd, desc, hr, sr, sl, z, drop, extra, residual=False):
     t = extra['t'][sl]
     if not residual:
-        return O.p_losses_ddpm(sdd, desc, extra['tab'], hr, sr, t, z, conditional=extra['conditional'], dropout=drop)
+        return O.p_losses_ddpm(sdd, desc, extra['tab'], hr, sr, t.to(hr.device), z, conditional=extra['conditional'], dropout=drop)
     a = torch.from_numpy(extra['tab']['sqrt_alphas_cumprod'])[t.cpu()].view(-1, 1, 1, 1).to(hr)
     s = torch.from_numpy(extra['tab']['sqrt_one_minus_alphas_cumprod'])[t.cpu()].view(-1, 1, 1, 1).to(hr)
     x_noisy = a * hr + s * z
