@@ -335,7 +335,8 @@ def roofline_from_profile(netG, x, cond, reps=3):
              155: 'k_conv3x3_halo<2,2,false,false,1,2>', 157: 'k_conv3x3_halo<2,2,true,false,1,2>',
              156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
              355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
-             455: 'k_conv3x3_wino<0>'}
+             455: 'k_conv3x3_wino<0,false,false,false>', 465: 'k_conv3x3_wino<0,false,true,false>',
+             555: 'k_conv3x3_wino<0,false,false,true>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -350,13 +351,9 @@ def roofline_from_profile(netG, x, cond, reps=3):
     kname = 'sr3::' + names[dom].replace(',', ', ')
 
     def by_kernel(table):
-        # the committed summaries carry the symbol of the tree they were recorded on: exact name first, then the same
-        # template with other trailing arguments (k_conv3x3_wino<0> was recorded before the kernel gained its DROP argument)
-        if kname in table:
-            return table[kname]
-        stem = kname[:-1] if kname.endswith('>') else kname
-        hits = [v for k, v in table.items() if isinstance(v, dict) and k.startswith(stem) and 'true' not in k[len(stem):]]
-        return hits[0] if len(hits) == 1 else None
+        # the committed summaries are keyed by the exact kernel symbol of the tree they were recorded on (tools/round_profile.sh
+        # after the last kernel change of the round): no match, no number
+        return table.get(kname)
     try:        # HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/)
         with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_hbm_traffic.json')) as f:
             traffic = by_kernel(json.load(f))['hbm_bytes_per_launch']
@@ -368,8 +365,8 @@ def roofline_from_profile(netG, x, cond, reps=3):
         counters = {'dominant_kernel': by_kernel(sq), 'attention': sq.get('attention')}
     except (OSError, ValueError):
         pass
-    is_wino = dom == 455
-    is_split = (not is_wino) and names[dom].split(',')[4] == '1'
+    is_wino = dom in (455, 465, 555)
+    is_split = dom == 555 or ((not is_wino) and names[dom].split(',')[4] == '1')
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
     # Winograd F(2x2,3x3): 16 multiplies per 2x2 output block and (cin, cout) pair instead of 36, so the MFMA pipe executes
@@ -377,14 +374,15 @@ def roofline_from_profile(netG, x, cond, reps=3):
     # fp32 MFMA roof (a fraction of a roof, <= 1); the direct-convolution-equivalent rate is reported beside it.
     executed = achieved / 2.25 if is_wino else achieved
     # step level: the floor the design chose = (Winograd FLOPs / 2.25 + all other contraction FLOPs) / peak
-    wino_fl = agg[455][1] / reps if 455 in agg else 0.0
+    wino_fl = sum(agg[k][1] for k in (455, 465, 555) if k in agg) / reps
     all_fl = sum(a[1] for a in agg.values()) / reps
     floor_ms = (wino_fl / 2.25 + (all_fl - wino_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
     # algorithmic HBM bytes of the dominant kernel's launches (each input / residual / output tensor and the transformed
     # filters once per launch), from the plan's own launch list
     alg_bytes = None
     try:
-        ops = [o for o in plan.op_list(B) if o['kind'] == 50 and o['tile_cfg'] == 11] if is_wino else []
+        ops = [o for o in plan.op_list(B) if o['kind'] == 50 and o['tile_cfg'] == {455: 11, 465: 11, 555: 12}[dom]
+               and (o['h_out'] == 8) == (dom == 465)] if is_wino else []
         if ops:
             tot = 0.0
             for o in ops:
@@ -412,10 +410,11 @@ def roofline_from_profile(netG, x, cond, reps=3):
                 all_halo_kernels_tflops=all_tf, sq_counters=counters, by_op_kind=detail)
 
 
-def split_bf16_leg(netG, st, T, dev, steps=200):
-    """Secondary, NOT the headline: the same reverse step with the opt-in `split_bf16` plan option (halo-tile
-    convs with Cout > 64 on v_mfma_f32_32x32x16_bf16, each fp32 operand split into three bf16 terms, six products,
-    fp32 accumulate).  Reports its step time and how far its eps is from the exact-fp32 path's on the same input."""
+def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16'):
+    """Secondary, NOT the headline: the same reverse step with an opt-in plan option that moves contractions onto
+    v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six products, fp32 accumulate):
+    `split_bf16` (round 1: the direct halo-tile convs with Cout > 64) or `wino_split` (round 4: the Winograd kernel's SPLIT
+    instantiation).  Reports its step time and how far its eps is from the exact-fp32 path's on the same input."""
     import torch
     un = netG.denoise_fn
     cond = st['cond']
@@ -425,7 +424,7 @@ def split_bf16_leg(netG, st, T, dev, steps=200):
     x = torch.randn(shape, device=dev, generator=g)
     tm = torch.full((B, 1), 0.6, device=dev) if un.variant == 'sr3' else torch.full((B,), 900, dtype=torch.long, device=dev)
     eps_exact = un(x, tm, cond=cond).clone()
-    un.plan.set_option('split_bf16', 1)
+    un.plan.set_option(option, 1)
     try:
         eps_split = un(x, tm, cond=cond).clone()
         st2 = netG._loop_state(shape, None if cond is None else shape, dev)
@@ -444,14 +443,14 @@ def split_bf16_leg(netG, st, T, dev, steps=200):
         ms = (time.perf_counter() - t0) / steps * 1e3
         finite = bool(torch.isfinite(st2['img']).all().item())
     finally:
-        un.plan.set_option('split_bf16', 0)
+        un.plan.set_option(option, 0)
         netG._loop_cache = {}
     fl = un.plan.forward_flops(B)
     return dict(ms_per_step=ms, images_per_s_per_gpu=B / (T * ms * 1e-3), step_tflops_equiv=fl / (ms * 1e-3) / 1e12,
                 steps=steps, output_finite=finite,
                 eps_max_abs_diff_vs_exact_fp32=float((eps_split - eps_exact).abs().max().item()),
                 eps_max_abs=float(eps_exact.abs().max().item()),
-                note='opt-in plan option split_bf16=1; not used for `value`')
+                note='opt-in plan option %s=1; not used for `value`' % option)
 
 
 def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
@@ -629,6 +628,8 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the bounded legs of the other BASELINE.json configurations (SR3 64->512 batch 4, DDPM-128 batch 32)')
     ap.add_argument('--no-split-leg', action='store_true', help='(default now) skip the secondary split_bf16 measurement')
+    ap.add_argument('--no-wino-split-leg', action='store_true',
+                    help='skip the secondary measurement of the wino_split plan option (Winograd on the bf16 MFMA, 3-way split)')
     ap.add_argument('--split-leg', action='store_true',
                     help='also time the opt-in split_bf16 plan option (direct halo kernels on bf16 MFMA; superseded by the fp32 '
                          'Winograd path, which is faster and exact-fp32 arithmetic)')
@@ -734,6 +735,12 @@ def main():
             rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'])
         except Exception as e:
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    if rank == 0 and not a.no_wino_split_leg and not a.split_bf16:
+        try:
+            rec['wino_split'] = split_bf16_leg(netG, st, T, dev, option='wino_split')
+            rec['wino_split']['dtype'] = 'f32 via 3xbf16 split (Winograd F(2x2,3x3) on v_mfma_f32_32x32x16_bf16)'
+        except Exception as e:                     # the secondary leg must never cost the headline line
+            rec['wino_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and a.split_leg and not a.no_split_leg and not a.split_bf16:
         try:
             rec['split_bf16'] = split_bf16_leg(netG, st, T, dev)

@@ -324,9 +324,22 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     hinfo_r[j] = hinfo_of(j, tid);
     hpix[j] = -1;
   }
-  auto hinfo = [&](int j) { return hinfo_r[j]; };
+  // SPLIT has no registers for these six values across its main loop: once a tile's exchange block is free (prologue) they are
+  // parked in LDS, in the part of that block the raw tiles do not use -- [k][thread], every thread reads only what it wrote --
+  // and `lds_tab` switches the accessors over; the next tile's values are computed into the registers again in the epilogue
+  int* ptab = reinterpret_cast<int*>(smem + 2 * GE::RAW_F);
+  static_assert(2 * GE::RAW_F + 2 * WHI * WNT + 3 * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation");
+  bool lds_tab = false;
+  auto hinfo = [&](int j) {
+    if (SPLIT && lds_tab) {
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      return ptab[j * WNT + t_];
+    }
+    return hinfo_r[j];
+  };
   auto pixel_of = [&](int j) {                    // source pixel of staging item j of the current tile (-1: zero padding)
-    const int hj = hinfo(j);
+    const int hj = hinfo_r[j];
     int hy = (hj >> 16) & 0xff, hx = (hj >> 24) & 0xff;
     int bi = b0;
     if (NB4) {                                      // halo block (hy / 10, hx / 10) of the 2 x 2 image grid
@@ -338,10 +351,30 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     return ok ? (bi * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
   };
   auto set_pixels = [&]() {
+    if (SPLIT) {                                    // back to registers for the next tile's prefetch (recomputed: not live across
+      lds_tab = false;                              // the main loop)
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+#pragma unroll
+      for (int j = 0; j < WHI; ++j) hinfo_r[j] = hinfo_of(j, t_);
+    }
 #pragma unroll
     for (int j = 0; j < WHI; ++j) hpix[j] = pixel_of(j);
   };
-  auto hpx = [&](int j) { return hpix[j]; };
+  auto hpx = [&](int j) {
+    if (SPLIT && lds_tab) {
+      int t_ = tid;
+      asm volatile("" : "+v"(t_));
+      return ptab[(WHI + j) * WNT + t_];
+    }
+    return hpix[j];
+  };
+  auto park_items = [&]() {
+    if (!SPLIT) return;
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) { ptab[j * WNT + tid] = hinfo_r[j]; ptab[(WHI + j) * WNT + tid] = hpix[j]; }
+    lds_tab = true;
+  };
   f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
   f32x4 rh2[WHI];           // ... of the tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
   auto load_raw = [&](int chunk, f32x4 (&r)[WHI]) {
@@ -593,6 +626,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+    park_items();
     store_raw(raw0, c_begin, rh, cs_);
     if (nck > 1) store_raw(raw1, c_begin + 1, rh2, cs_);
     load_raw(c2, rh);
@@ -609,15 +643,16 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     //   barrier: raw[i & 1] is fully consumed -> stage chunk i + 2 into it; chunk i + 1's tile is visible
     //   reads (m0,kk0) of chunk i + 1 | MFMA (m1,kk1) | finish    U fragments kk1 of chunk i + 1
     if constexpr (SPLIT) {
-      // Units are whole tile blocks (m) of a chunk: K = 16 is one bf16 MFMA.  Per unit: the transform of the NEXT unit in two
-      // halves (the six LDS reads of half chunk kk = 0 before the first MFMA group, those of kk = 1 before the second -- 24
-      // registers in flight instead of 48), its 3 x bf16 split after the second group; the U fragments of the next chunk are
-      // fetched per position right after that position's last MFMA of the chunk (one buffer, >= 1 k cycles ahead of use).
-      //   reads kk0 (m1)       | MFMA (m0, pos a) x 12 | finish kk0 ; reads kk1 (m1)
-      //                        | MFMA (m0, pos b) x 12 | finish kk1 ; split -> V (m1)
-      //   barrier ; stage chunk i + 2 ; reads kk0 (m0 of chunk i + 1)
-      //                        | MFMA (m1, pos a) x 12 | U pos a of chunk i + 1 ; finish kk0 ; reads kk1
-      //                        | MFMA (m1, pos b) x 12 | U pos b of chunk i + 1 ; finish kk1 ; split -> V (m0, i + 1)
+      // Units are whole tile blocks (m) of a chunk: K = 16 is ONE bf16 MFMA per (position, n block, product).  Per unit two MFMA
+      // groups of 12 (position a, position b); behind each group the transform of half of the NEXT unit (kk = 0 / kk = 1: six LDS
+      // reads, row + column pass), behind the second also the 3 x bf16 split of the next unit's operands.  The U fragments of
+      // the next chunk are fetched per position right after that position's last MFMA of the chunk: one buffer, refilled >= 1 k
+      // cycles ahead of its next use.
+      //   MFMA (m0, a) x 12 | reads kk0 (m1), finish ; fetch V_b (m0) from LDS
+      //   MFMA (m0, b) x 12 | reads kk1 (m1), finish ; park V_b (m1) in LDS ; split -> V_a (m1)
+      //   barrier ; stage chunk i + 2
+      //   MFMA (m1, a) x 12 | U pos a of chunk i + 1 ; reads kk0 (m0 of chunk i + 1), finish ; fetch V_b (m1)
+      //   MFMA (m1, b) x 12 | U pos b of chunk i + 1 ; reads kk1, finish ; park V_b (m0, i + 1) ; split -> V_a (m0, i + 1)
       bf16x8 vsa[3], vsb[3];
       f32x4 va0, vb0, va1, vb1;
       {
@@ -628,11 +663,24 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         t_finish(da, db, va1, vb1);
         split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
       }
-      // (position b stays in fp32 -- wb0, wb1 -- until its own MFMA group: 8 registers instead of 12 across group a.  No LDS read
-      // is in flight across an MFMA group -- this instantiation has no registers for that: the six reads of a half-unit are
-      // issued right behind a group, with the other position's split between them and their use where there is one; the
-      // partner wave of the SIMD owns the matrix pipe meanwhile)
-      f32x4 wb0 = vb0, wb1 = vb1;
+      // Registers: this instantiation has none to spare (128 accumulators + 48 of U + the operands), so (a) no LDS read is in
+      // flight across an MFMA group -- the six reads of a half-unit are issued right behind a group (the partner wave of the
+      // SIMD owns the matrix pipe meanwhile), and (b) position b's split planes wait in LDS ([plane][thread], 16 bytes each, in
+      // the free part of the exchange block) from the moment they are built until their own MFMA group: 12 registers across group a.
+      bf16x8* vpark = reinterpret_cast<bf16x8*>(ptab + 2 * WHI * WNT);
+      auto park_b = [&]() {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        bf16x8 h, m, l;
+        split3x8(vb0, vb1, h, m, l);
+        vpark[t_] = h; vpark[WNT + t_] = m; vpark[2 * WNT + t_] = l;
+      };
+      auto fetch_b = [&]() {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        vsb[0] = vpark[t_]; vsb[1] = vpark[WNT + t_]; vsb[2] = vpark[2 * WNT + t_];
+      };
+      park_b();
       for (int i = 0; i < nck; ++i) {
         float* rcur = (i & 1) ? raw1 : raw0;
         const float* rnext = (i & 1) ? raw0 : raw1;
@@ -640,17 +688,19 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         f32x4 da[3], db[3];
         mfma_split(0, 0, vsa);
         __builtin_amdgcn_sched_barrier(0);
-        split3x8(wb0, wb1, vsb[0], vsb[1], vsb[2]);
-        __builtin_amdgcn_sched_barrier(0);
         t_load(rcur, 1, 0, da, db);
         t_finish(da, db, va0, vb0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_b();
         __builtin_amdgcn_sched_barrier(0);
         mfma_split(0, 1, vsb);
         __builtin_amdgcn_sched_barrier(0);
         t_load(rcur, 1, 1, da, db);
         t_finish(da, db, va1, vb1);
+        __builtin_amdgcn_sched_barrier(0);
+        park_b();
+        __builtin_amdgcn_sched_barrier(0);
         split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
-        wb0 = vb0; wb1 = vb1;
         __syncthreads();
         if (i + 2 < nck) {
           store_raw(rcur, c_begin + i + 2, rh, cs_);
@@ -659,13 +709,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         __builtin_amdgcn_sched_barrier(0);
         mfma_split(1, 0, vsa);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_us(c_begin + i + 1, 0);
-        split3x8(wb0, wb1, vsb[0], vsb[1], vsb[2]);
-        __builtin_amdgcn_sched_barrier(0);
         if (more) {
+          load_us(c_begin + i + 1, 0);
           t_load(rnext, 0, 0, da, db);
           t_finish(da, db, va0, vb0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_b();
         __builtin_amdgcn_sched_barrier(0);
         mfma_split(1, 1, vsb);
         __builtin_amdgcn_sched_barrier(0);
@@ -673,8 +723,10 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           load_us(c_begin + i + 1, 1);
           t_load(rnext, 0, 1, da, db);
           t_finish(da, db, va1, vb1);
+          __builtin_amdgcn_sched_barrier(0);
+          park_b();
+          __builtin_amdgcn_sched_barrier(0);
           split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
-          wb0 = vb0; wb1 = vb1;
         }
       }
     } else {

@@ -226,22 +226,7 @@ static int build_structure(sr3_plan* P) {
   P->fin_w = add_conv(P, "final_conv.block.3.weight", out_ch, P->fin_cin, 3, &cur);
   P->fin_b = add_vec(P, "final_conv.block.3.bias", out_ch, &cur);
   P->param_floats = (cur + 3) & ~(size_t)3;
-  // derived (Winograd) filters of every 3x3 stride-1 conv: the two convs of each ResnetBlock and the Upsample convs
-  {
-    size_t dcur = 0;
-    auto reg = [&](size_t w, int Cout, int Cin) {
-      if (Cin & 3) return;
-      P->derived.push_back({w, Cout, Cin, dcur});
-      P->derived_of[w] = dcur;
-      dcur += wino_weight_floats(Cout, Cin);
-    };
-    for (auto* v : {&P->downs, &P->mid, &P->ups})
-      for (auto& L : *v) {
-        if (L.kind == 1) { reg(L.res.c1_w, L.res.cout, L.res.cin); reg(L.res.c2_w, L.res.cout, L.res.cout); }
-        else if (L.kind == 3) reg(L.w, L.cout, L.cin);
-      }
-    P->derived_floats = dcur;
-  }
+  layout_derived(P);
 
   // every GroupNorm must divide
   auto chk = [&](int c) { return c % d.norm_groups == 0; };
@@ -407,6 +392,13 @@ struct Builder {
     if (wino_ok(c, w, q0 >= 0, o.has_drop)) {
       o.tile_cfg = 11;
       o.wino_off = P->derived_of[w];
+      // plan option wino_split: the 3 x bf16 split instantiation where it exists (inference, one-image tile, no dropout); its
+      // filters sit behind the conv's fp32 ones
+      WinoGeom wg;
+      if (P->wino_split && !train && !o.has_drop && wino_geometry(c, &wg) && wg.NB == 1) {
+        c.wino_split = 1;
+        o.wino_off += wino_weight_floats(Cout, C0 + C1);
+      }
     }
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
@@ -597,6 +589,29 @@ static void walk_forward(sr3_plan* P, Builder& bld, int cond_channels) {
     }
     bld.flops += 2.0 * B * S * S * (double)P->out_ch * bld.T[cur].C * 9;
   }
+}
+
+// derived (Winograd) filters of every 3x3 stride-1 conv: the two convs of each ResnetBlock and the Upsample convs.  Slot of a
+// conv: its fp32 fragment-major filters, followed -- plan option wino_split -- by the 3 x bf16 split form of the same filters
+// (both are kept: the four-image 8x8 tile, the dropout instantiation and the training plan read the fp32 form)
+void layout_derived(sr3_plan* P) {
+  P->derived.clear();
+  P->derived_of.clear();
+  size_t dcur = 0;
+  auto reg = [&](size_t w, int Cout, int Cin) {
+    if (Cin & 3) return;
+    P->derived.push_back({w, Cout, Cin, dcur});
+    P->derived_of[w] = dcur;
+    dcur += wino_weight_floats(Cout, Cin) + (P->wino_split ? wino_weight_floats(Cout, Cin, true) : 0);
+  };
+  for (auto* v : {&P->downs, &P->mid, &P->ups})
+    for (auto& L : *v) {
+      if (L.kind == 1) { reg(L.res.c1_w, L.res.cout, L.res.cin); reg(L.res.c2_w, L.res.cout, L.res.cout); }
+      else if (L.kind == 3) reg(L.w, L.cout, L.cin);
+    }
+  P->derived_floats = dcur;
+  P->derived_from = nullptr;
+  if (P->derived_bound_bytes < dcur * sizeof(float)) { P->derived_ptr = nullptr; P->derived_bound_bytes = 0; }   // re-bind a larger one
 }
 
 static int build_forward(sr3_plan* P, int B, int cond_channels) {
@@ -920,7 +935,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
   out->kind = (int)o.kind * 10;
   if (o.kind == OP_CONV) {
     const ConvParams& c = o.cp;
-    out->tile_cfg = o.tile_cfg; out->ksplit = o.ksplit;
+    out->tile_cfg = (o.tile_cfg == 11 && o.cp.wino_split) ? 12 : o.tile_cfg; out->ksplit = o.ksplit;
     out->ksize = c.ksize; out->stride = c.stride; out->upsample = c.ups;
     out->cin = c.C0 + c.C1; out->cout = c.Cout; out->h_out = c.Ho; out->w_out = c.Wo;
     out->fused_res_conv_cin = o.has_x2 ? c.x2_C0 + c.x2_C1 : 0;
@@ -951,6 +966,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "fuse_res")) slot = &plan->fuse_res;
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
+  else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
   const int prev = *slot;
@@ -959,6 +975,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
+  if (slot == &plan->wino_split && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }
@@ -994,8 +1011,13 @@ int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) 
   if (!plan || !params) { set_error("null argument"); return SR3_E_BADARG; }
   if (!plan->derived_ptr) { set_error("no derived buffer bound"); return SR3_E_BADARG; }
   for (const auto& d : plan->derived) {
-    const int rc = wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
+    int rc = wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
     if (rc) return rc;
+    if (plan->wino_split) {
+      rc = wino_transform_weights(params + d.w, d.Cout, d.Cin, plan->derived_ptr + d.off + wino_weight_floats(d.Cout, d.Cin),
+                                  static_cast<hipStream_t>(stream), true);
+      if (rc) return rc;
+    }
   }
   plan->derived_from = params;
   return SR3_OK;
@@ -1062,10 +1084,13 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
       if (o.kind == OP_CONV) {
         // 51-54 im2col kernel tile configs; 55/56 halo-tile 3x3 kernel (57/58: with the fused 1x1 segment)
         //        155-158: the same four on the opt-in split-bf16 instantiations; 255/257: the 8-wave 256x128 tile
-        //        (cfg 9), 355/357: its split-bf16 twin (cfg 10); 455: the Winograd F(2x2,3x3) kernel (cfg 11)
+        //        (cfg 9), 355/357: its split-bf16 twin (cfg 10); 455: the Winograd F(2x2,3x3) kernel (cfg 11), 465: its four-image
+        //        tile of the 8x8 maps, 555: its 3 x bf16 split instantiation (plan option wino_split)
         {
           static const int base[13] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305, 405, 505};
-          kind += base[o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
+          kind += base[(o.tile_cfg == 11 && o.cp.wino_split) ? 12 : o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
+          WinoGeom wg;
+          if (o.tile_cfg == 11 && wino_geometry(o.cp, &wg) && wg.NB != 1) kind += 10;      // 465: the four-image 8x8 tile
         }
         const ConvParams& c = o.cp;
         fl = 2.0 * c.B * c.Ho * c.Wo * (double)c.Cout * ((double)(c.C0 + c.C1) * c.ksize * c.ksize + (o.has_x2 ? c.x2_C0 + c.x2_C1 : 0));
@@ -1127,15 +1152,17 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
   c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
+  const bool wsplit = tile_cfg == 12;         // 12 = tile 11 on the 3 x bf16 split instantiation
+  if (wsplit) { tile_cfg = 11; c.wino_split = 1; }
   if (tile_cfg == 11 && (ksize != 3 || stride != 1)) { set_error("conv: the Winograd kernel does not fit this problem (3x3 stride 1 only)"); return SR3_E_UNSUPPORTED; }
   if (tile_cfg == 11) {
     // Winograd form through the per-op entry: the transformed filters are derived here, behind the split-K slabs in
     // `scratch` (sr3_conv_scratch_bytes accounts for them); a plan keeps them in its derived buffer instead.
     const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
-    const size_t ub = wino_weight_floats(Cout, c.C0 + c.C1) * sizeof(float);
+    const size_t ub = wino_weight_floats(Cout, c.C0 + c.C1, wsplit) * sizeof(float);
     if (!scratch || scratch_bytes < slab + ub || ksize != 3) { set_error("conv: Winograd scratch too small (%zu < %zu)", scratch_bytes, slab + ub); return SR3_E_NOMEM; }
     float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
-    const int rc = wino_transform_weights(w, Cout, c.C0 + c.C1, u, static_cast<hipStream_t>(stream));
+    const int rc = wino_transform_weights(w, Cout, c.C0 + c.C1, u, static_cast<hipStream_t>(stream), wsplit);
     if (rc) return rc;
     c.wino_u = u;
 #ifdef SR3_WINO_ABLATIONS
@@ -1206,9 +1233,9 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
   ConvParams c;
   memset(&c, 0, sizeof(c));
   c.B = B; c.Ho = Ho; c.Wo = Wo; c.C0 = Cin; c.Cout = Cout; c.ksize = ksize;
-  if (tile_cfg == 11) {      // Winograd: the geometry (hence the split) needs the stride-1 input dims; + the derived filters
+  if (tile_cfg == 11 || tile_cfg == 12) {      // Winograd: the geometry (hence the split) needs the stride-1 input dims; + the derived filters
     c.Hs = Ho; c.Ws = Wo; c.stride = 1;
-    return conv_splitk_bytes(c, tile_cfg, ksplit) + wino_weight_floats(Cout, Cin) * sizeof(float);
+    return conv_splitk_bytes(c, 11, ksplit) + wino_weight_floats(Cout, Cin, tile_cfg == 12) * sizeof(float);
   }
   // the entry does not know the stride: take the larger of the stride-1 (halo kernel eligible) and the im2col sizing
   const size_t a = conv_splitk_bytes(c, tile_cfg, ksplit);
@@ -1226,6 +1253,7 @@ int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int
   memset(&c, 0, sizeof(c));
   c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = 1; c.ksize = 3; c.Ho = Hs << ups; c.Wo = Ws << ups;
   c.Cout = Cout; c.C0 = Cin;
+  if (tile_cfg == 12) tile_cfg = 11;
   conv_pick(c, tile_cfg, ksplit);
   if (ksplit > 1) {
     const int rpb = splitk_rows_per_block(c, true);

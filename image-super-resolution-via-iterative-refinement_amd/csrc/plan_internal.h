@@ -103,6 +103,7 @@ struct sr3_plan {
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
                              // 68 TF vs 72 TF for the im2col kernel's 64x64 tile on this network's layers, so off by default
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
+  int wino_split = 0;        // ... on its 3 x bf16 split instantiation (bf16 MFMA, fp32-class results) where that exists
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;
@@ -146,4 +147,5 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid,
                 const DropCfg* drop = nullptr);
 int build_train(sr3_plan* P, int B, int cond_channels);
+void layout_derived(sr3_plan* P);
 }  // namespace sr3

@@ -111,6 +111,32 @@ def test_c2_batch16_forward_and_graph_step():
     netG.denoise_fn.plan.set_option('winograd', 1)
 
 
+def test_c2_batch16_wino_split_option():
+    """Gate of the opt-in `wino_split` plan option at the headline configuration: the Winograd convs of maps >= 16x16 on the
+    kernel's 3 x bf16 split instantiation (tile 12).  Same stated tolerance as the exact-fp32 plan for the forward and for one
+    replay of the production graph, and the forward's error against the CPU oracle must not exceed 1.5x the exact-fp32 plan's
+    on the same input (both are printed)."""
+    from oracle import sr3_oracle as O
+    B = 16
+    netG, sd, desc, opt, c = _build('sr3_16_128')
+    d = G.dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 6, 128, 128, generator=g)
+    lvl = torch.linspace(0.05, 0.999, B).view(B, 1)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, desc, x, lvl)
+    e_fp32 = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (fp32 Winograd)')
+    netG.denoise_fn.plan.set_option('wino_split', 1)
+    cfgs = _cfgs(netG, B)
+    assert (12, 1) in cfgs and (12, 2) in cfgs and (11, 8) in cfgs and not any(t == 11 and k < 8 for t, k in cfgs), sorted(set(cfgs))
+    e_split = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (wino_split)')
+    print('C2 batch 16: eps max abs err vs the CPU oracle: fp32 Winograd plan %.2e, wino_split plan %.2e (|ref|max %.2f)'
+          % (e_fp32, e_split, ref.abs().max().item()))
+    assert e_split <= 1.5 * e_fp32 + 2e-7, (e_split, e_fp32)
+    _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2 wino_split')
+    netG.denoise_fn.plan.set_option('wino_split', 0)
+
+
 def test_c4_batch4_graph_step():
     B = 4
     netG, sd, desc, opt, c = _build('sr3_64_512')

@@ -72,6 +72,24 @@ def test_unet_forward_split_bf16_option(name):
 
 
 @pytest.mark.parametrize('name', NAMES)
+def test_unet_forward_wino_split_option(name):
+    """Opt-in `wino_split` plan option (the Winograd kernel's 3 x bf16 split instantiation) on the reference-generated
+    vectors: same stated tolerance; toggling it back restores the exact-fp32 result bit for bit."""
+    m, g, sd = build(name)
+    un = m.netG.denoise_fn
+    d = G.dev()
+    x, t = torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d)
+    e0 = un(x, t).clone()
+    un.plan.set_option('wino_split', 1)
+    has12 = any(o['tile_cfg'] == 12 for o in un.plan.op_list(x.shape[0]))
+    e1 = un(x, t).clone()
+    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (wino_split)')
+    assert has12 == (not torch.equal(e0, e1)) or not has12
+    un.plan.set_option('wino_split', 0)
+    assert torch.equal(un(x, t), e0)
+
+
+@pytest.mark.parametrize('name', NAMES)
 def test_unet_forward_buffer_reuse_matches(name):
     """The liveness-planned workspace (buffers recycled) gives the same eps as keep_all."""
     m, g, sd = build(name)
