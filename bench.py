@@ -43,7 +43,7 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-PROFILE_ROUND = 'r03'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
+PROFILE_ROUND = 'r04'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
 
 # The `model` subtrees of the reference's configs (config/sr_sr3_16_128.json:39-77, sr_sr3_64_512.json:39-80,
 # sample_ddpm_128.json:38-79) + the batch sizes BASELINE.json quotes.
@@ -376,7 +376,10 @@ def roofline_from_profile(netG, x, cond, reps=3):
     # step level: the floor the design chose = (Winograd FLOPs / 2.25 + all other contraction FLOPs) / peak
     wino_fl = sum(agg[k][1] for k in (455, 465, 555) if k in agg) / reps
     all_fl = sum(a[1] for a in agg.values()) / reps
-    floor_ms = (wino_fl / 2.25 + (all_fl - wino_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+    # (the 3 x bf16 split kernels' share at their own roof, everything else at the fp32 MFMA roof)
+    split_fl = (agg[555][1] / reps if 555 in agg else 0.0)
+    floor_ms = ((wino_fl - split_fl) / 2.25 + (all_fl - wino_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3 + \
+               (split_fl / 2.25) / (BF16_MFMA_PEAK_TFLOPS / 6.0 * 1e12) * 1e3
     # algorithmic HBM bytes of the dominant kernel's launches (each input / residual / output tensor and the transformed
     # filters once per launch), from the plan's own launch list
     alg_bytes = None
@@ -393,15 +396,21 @@ def roofline_from_profile(netG, x, cond, reps=3):
     except Exception:
         pass
     extra = dict(direct_equiv_tflops=achieved, executed_mfma_tflops=executed,
-                 step_floor_ms_at_fp32_mfma_peak=floor_ms, launches_ms_per_forward=total_ms,
+                 step_floor_ms_at_mfma_peaks=floor_ms, launches_ms_per_forward=total_ms,
                  step_frac_of_winograd_roof=(floor_ms / total_ms if total_ms > 0 else None),
                  algorithmic_bytes_per_launch=alg_bytes,
                  traffic_over_algorithmic=(traffic / alg_bytes if traffic and alg_bytes else None),
-                 note='achieved / frac = MFMA FLOPs actually issued (direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) vs the fp32 '
-                      'MFMA peak; direct_equiv_tflops = SURVEY 8d algorithmic FLOPs / time (can exceed the peak)')
-    return dict(bound='mfma', kernel=names[dom] + (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
-                                                   else (' (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, persistent workgroups)' if is_wino
-                                                         else ' (v_mfma_f32_32x32x2_f32)')), achieved=executed,
+                 note=('achieved / frac = fp32 multiply-adds the kernel evaluates (direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)), '
+                       'each as six bf16 MFMA products, vs the bf16 MFMA peak / 6 = %.1f TFLOP/s fp32-equivalent; this instantiation is '
+                       'bound by its VALU / LDS work (staging, transform, 3-way split), not by the matrix pipe; direct_equiv_tflops = '
+                       'SURVEY 8d algorithmic FLOPs / time' % (BF16_MFMA_PEAK_TFLOPS / 6.0)) if (is_split and is_wino) else
+                      ('achieved / frac = MFMA FLOPs actually issued (direct-conv FLOPs / 2.25 for Winograd F(2x2,3x3)) vs the fp32 '
+                       'MFMA peak; direct_equiv_tflops = SURVEY 8d algorithmic FLOPs / time (can exceed the peak)'))
+    return dict(bound='mfma', kernel=names[dom] + (' (Winograd F(2x2,3x3), 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, persistent workgroups)'
+                                                   if (is_split and is_wino) else
+                                                   (' (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)' if is_split
+                                                    else (' (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, persistent workgroups)' if is_wino
+                                                          else ' (v_mfma_f32_32x32x2_f32)'))), achieved=executed,
                 peak=peak, unit='TFLOP/s', frac=executed / peak, traffic=traffic, **extra,
                 traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/%s_bench_hbm_pmc.csv'
                              % PROFILE_ROUND,
@@ -410,7 +419,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
                 all_halo_kernels_tflops=all_tf, sq_counters=counters, by_op_kind=detail)
 
 
-def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16'):
+def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, restore=0, with_roofline=False):
     """Secondary, NOT the headline: the same reverse step with an opt-in plan option that moves contractions onto
     v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six products, fp32 accumulate):
     `split_bf16` (round 1: the direct halo-tile convs with Cout > 64) or `wino_split` (round 4: the Winograd kernel's SPLIT
@@ -423,8 +432,9 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16'):
     g = torch.Generator(device=dev).manual_seed(77)
     x = torch.randn(shape, device=dev, generator=g)
     tm = torch.full((B, 1), 0.6, device=dev) if un.variant == 'sr3' else torch.full((B,), 900, dtype=torch.long, device=dev)
-    eps_exact = un(x, tm, cond=cond).clone()
-    un.plan.set_option(option, 1)
+    eps_exact = un(x, tm, cond=cond).clone()         # (the plan the headline ran on)
+    un.plan.set_option(option, value)
+    roof = None
     try:
         eps_split = un(x, tm, cond=cond).clone()
         st2 = netG._loop_state(shape, None if cond is None else shape, dev)
@@ -442,15 +452,17 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16'):
         torch.cuda.synchronize(dev)
         ms = (time.perf_counter() - t0) / steps * 1e3
         finite = bool(torch.isfinite(st2['img']).all().item())
+        if with_roofline:
+            roof = roofline_from_profile(netG, st2['img'], st2['cond'])
     finally:
-        un.plan.set_option(option, 0)
+        un.plan.set_option(option, restore)
         netG._loop_cache = {}
     fl = un.plan.forward_flops(B)
     return dict(ms_per_step=ms, images_per_s_per_gpu=B / (T * ms * 1e-3), step_tflops_equiv=fl / (ms * 1e-3) / 1e12,
                 steps=steps, output_finite=finite,
-                eps_max_abs_diff_vs_exact_fp32=float((eps_split - eps_exact).abs().max().item()),
-                eps_max_abs=float(eps_exact.abs().max().item()),
-                note='opt-in plan option %s=1; not used for `value`' % option)
+                eps_max_abs_diff_vs_headline_plan=float((eps_split - eps_exact).abs().max().item()),
+                eps_max_abs=float(eps_exact.abs().max().item()), roofline=roof,
+                note='plan option %s=%d; not used for `value`' % (option, value))
 
 
 def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
@@ -497,7 +509,7 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
 
 
-def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000):
+def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=False):
     """define_G of a BASELINE.json network (random init, seed 0), its reverse-step hipGraph captured at batch B."""
     import torch
     import model.networks as networks
@@ -511,6 +523,8 @@ def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000):
     netG.denoise_fn.plan.set_option('fuse_stats', 1)
     if split_bf16:
         netG.denoise_fn.plan.set_option('split_bf16', 1)
+    if exact_fp32:
+        netG.denoise_fn.plan.set_option('wino_split', 0)
     S = cfg['size']
     torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
     shape = (B, 3, S, S)
@@ -628,8 +642,10 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the bounded legs of the other BASELINE.json configurations (SR3 64->512 batch 4, DDPM-128 batch 32)')
     ap.add_argument('--no-split-leg', action='store_true', help='(default now) skip the secondary split_bf16 measurement')
-    ap.add_argument('--no-wino-split-leg', action='store_true',
-                    help='skip the secondary measurement of the wino_split plan option (Winograd on the bf16 MFMA, 3-way split)')
+    ap.add_argument('--no-exact-leg', action='store_true',
+                    help='skip the secondary measurement with plan option wino_split = 0 (every Winograd conv on the fp32 MFMA)')
+    ap.add_argument('--exact-fp32', action='store_true',
+                    help='run the HEADLINE leg with wino_split = 0 (dtype is then reported as f32)')
     ap.add_argument('--split-leg', action='store_true',
                     help='also time the opt-in split_bf16 plan option (direct halo kernels on bf16 MFMA; superseded by the fp32 '
                          'Winograd path, which is faster and exact-fp32 arithmetic)')
@@ -683,7 +699,7 @@ def main():
     T = 2000
     B = a.batch or cfg['batch']
     S = cfg['size']
-    netG, st = build_sampler(a.config, B, dev, rank, a.split_bf16, T)
+    netG, st = build_sampler(a.config, B, dev, rank, a.split_bf16, T, a.exact_fp32)
     elapsed = time_replays(st, a.steps, a.warmup, T, dist, dev)
     finite = bool(torch.isfinite(st['img']).all().item())
     ms_per_step = elapsed / a.steps * 1e3
@@ -696,7 +712,10 @@ def main():
         'metric': '%s images/sec (2000-step sample)' % cfg['title'], 'value': images_per_s, 'unit': 'images/s',
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 via 3xbf16 split MFMA' if a.split_bf16 else 'f32', 'data': 'synthetic',
+        # fp32 tensors and fp32 accumulation everywhere; the Winograd contractions of maps >= 16x16 (the dominant kernel) evaluate
+        # each fp32 product as six bf16 MFMA products of 3-way split operands (plan option wino_split, default on, gated in tests/);
+        # `exact_fp32` below is the same step with that option off
+        'dtype': 'f32 via 3xbf16 split MFMA' if (a.split_bf16 or not a.exact_fp32) else 'f32', 'data': 'synthetic',
         'config': {'workload': '%s UNet (reference %s; BASELINE.json configs[%d]), batch %d per GPU, 2000-step p_sample_loop via '
                                'hipGraph replay; step = one reverse step of the batch; images/s = n_gpus*batch/(2000*t_step)'
                                % (cfg['title'], cfg['ref_json'], cfg['baseline_cfg'], B),
@@ -735,12 +754,13 @@ def main():
             rec['roofline'] = roofline_from_profile(netG, st['img'], st['cond'])
         except Exception as e:
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
-    if rank == 0 and not a.no_wino_split_leg and not a.split_bf16:
-        try:
-            rec['wino_split'] = split_bf16_leg(netG, st, T, dev, option='wino_split')
-            rec['wino_split']['dtype'] = 'f32 via 3xbf16 split (Winograd F(2x2,3x3) on v_mfma_f32_32x32x16_bf16)'
+    if rank == 0 and not a.no_exact_leg and not a.split_bf16 and not a.exact_fp32:
+        try:       # the same step with every Winograd conv on the exact-fp32 MFMA instantiation (plan option wino_split = 0)
+            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option='wino_split', value=0, restore=1,
+                                               with_roofline=not a.no_roofline)
+            rec['exact_fp32']['dtype'] = 'f32 (v_mfma_f32_32x32x2_f32 everywhere)'
         except Exception as e:                     # the secondary leg must never cost the headline line
-            rec['wino_split'] = {'error': '%s: %s' % (type(e).__name__, e)}
+            rec['exact_fp32'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and a.split_leg and not a.no_split_leg and not a.split_bf16:
         try:
             rec['split_bf16'] = split_bf16_leg(netG, st, T, dev)

@@ -39,6 +39,12 @@
 
 #include "sr3_common.h"
 
+#ifdef SR3_SPLIT_NOSB
+#define SR3_SB() do {} while (0)
+#else
+#define SR3_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace sr3 {
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -325,19 +331,12 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     hpix[j] = -1;
   }
   // SPLIT has no registers for these six values across its main loop: once a tile's exchange block is free (prologue) they are
-  // parked in LDS, in the part of that block the raw tiles do not use -- [k][thread], every thread reads only what it wrote --
-  // and `lds_tab` switches the accessors over; the next tile's values are computed into the registers again in the epilogue
-  int* ptab = reinterpret_cast<int*>(smem + 2 * GE::RAW_F);
+  // parked in LDS, in the part of that block the raw tiles do not use -- [item][thread], every thread reads only what it wrote --
+  // and re-read (three 8-byte reads) right before every staging step of the loop; the next tile's values are computed into the
+  // registers again in the epilogue
+  int* ptab = reinterpret_cast<int*>(smem + 2 * GE::RAW_F);       // [item][thread] of (hinfo, hpix)
   static_assert(2 * GE::RAW_F + 2 * WHI * WNT + 3 * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation");
-  bool lds_tab = false;
-  auto hinfo = [&](int j) {
-    if (SPLIT && lds_tab) {
-      int t_ = tid;
-      asm volatile("" : "+v"(t_));
-      return ptab[j * WNT + t_];
-    }
-    return hinfo_r[j];
-  };
+  auto hinfo = [&](int j) { return hinfo_r[j]; };
   auto pixel_of = [&](int j) {                    // source pixel of staging item j of the current tile (-1: zero padding)
     const int hj = hinfo_r[j];
     int hy = (hj >> 16) & 0xff, hx = (hj >> 24) & 0xff;
@@ -351,8 +350,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     return ok ? (bi * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups) : -1;
   };
   auto set_pixels = [&]() {
-    if (SPLIT) {                                    // back to registers for the next tile's prefetch (recomputed: not live across
-      lds_tab = false;                              // the main loop)
+    if (SPLIT) {                                    // (recomputed per tile: not live across the main loop)
       int t_ = tid;
       asm volatile("" : "+v"(t_));
 #pragma unroll
@@ -361,19 +359,22 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
     for (int j = 0; j < WHI; ++j) hpix[j] = pixel_of(j);
   };
-  auto hpx = [&](int j) {
-    if (SPLIT && lds_tab) {
-      int t_ = tid;
-      asm volatile("" : "+v"(t_));
-      return ptab[(WHI + j) * WNT + t_];
-    }
-    return hpix[j];
-  };
-  auto park_items = [&]() {
+  auto hpx = [&](int j) { return hpix[j]; };
+  typedef int int2_t __attribute__((ext_vector_type(2)));
+  auto park_items = [&]() {                        // SPLIT, prologue: registers -> LDS
     if (!SPLIT) return;
 #pragma unroll
-    for (int j = 0; j < WHI; ++j) { ptab[j * WNT + tid] = hinfo_r[j]; ptab[(WHI + j) * WNT + tid] = hpix[j]; }
-    lds_tab = true;
+    for (int j = 0; j < WHI; ++j) reinterpret_cast<int2_t*>(ptab)[j * WNT + tid] = int2_t{hinfo_r[j], hpix[j]};
+  };
+  auto fetch_items = [&]() {                       // SPLIT, main loop: LDS -> registers, right before a staging step
+    if (!SPLIT) return;
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) {
+      const int2_t v = reinterpret_cast<const int2_t*>(ptab)[j * WNT + t_];
+      hinfo_r[j] = v.x; hpix[j] = v.y;
+    }
   };
   f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
   f32x4 rh2[WHI];           // ... of the tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   bf16x8 us[2][2][3];
   const __bf16* ubase_s = nullptr;
   auto load_us = [&](int chunk, int pj) {
+    if ((DBG & 16) && chunk != c_begin) return;
     const __bf16* q = ubase_s + (size_t)chunk * 16 * (2 * WUS) + pj * (2 * WUS);
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -550,11 +552,24 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // accumulators between dependent MFMAs), smallest terms first
   auto mfma_split = [&](int m, int pj, const bf16x8 (&v)[3]) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    if (DBG & 1) {               // keep the operands live, issue no MFMA
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[pj][m][n][pl] += (float)v[pl][0] * (float)us[pj][n][pl][0];
+      return;
+    }
+#ifdef SR3_SPLIT_PRIO_GROUPS
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
       for (int n = 0; n < 2; ++n)
         acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v[PA[q]], us[pj][n][PB[q]], acc[pj][m][n], 0, 0, 0);
+#ifdef SR3_SPLIT_PRIO_GROUPS
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   auto mfma_unit = [&](int m, int kk, const f32x4& va, const f32x4& vb) {   // 16 MFMAs: tile block m, channels 8 kk .. 8 kk + 7
     if (DBG & 1) {               // keep the operands live, issue no MFMA
@@ -654,14 +669,23 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       //   MFMA (m1, a) x 12 | U pos a of chunk i + 1 ; reads kk0 (m0 of chunk i + 1), finish ; fetch V_b (m1)
       //   MFMA (m1, b) x 12 | U pos b of chunk i + 1 ; reads kk1, finish ; park V_b (m0, i + 1) ; split -> V_a (m0, i + 1)
       bf16x8 vsa[3], vsb[3];
-      f32x4 va0, vb0, va1, vb1;
+      f32x4 va0 = {0.f, 0.f, 0.f, 0.f}, vb0 = va0, va1 = va0, vb1 = va0;
+      auto sp3 = [&](const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
+        if (DBG & 128) {           // ablation: one conversion per value, no residuals
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (__bf16)(e < 4 ? lo[e] : hi[e - 4]);
+          m = h; l = h;
+          return;
+        }
+        split3x8(lo, hi, h, m, l);
+      };
       {
         f32x4 da[3], db[3];
         t_load(raw0, 0, 0, da, db);
         t_finish(da, db, va0, vb0);
         t_load(raw0, 0, 1, da, db);
         t_finish(da, db, va1, vb1);
-        split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+        sp3(va0, va1, vsa[0], vsa[1], vsa[2]);
       }
       // Registers: this instantiation has none to spare (128 accumulators + 48 of U + the operands), so (a) no LDS read is in
       // flight across an MFMA group -- the six reads of a half-unit are issued right behind a group (the partner wave of the
@@ -672,61 +696,86 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         int t_ = tid;
         asm volatile("" : "+v"(t_));
         bf16x8 h, m, l;
-        split3x8(vb0, vb1, h, m, l);
+        sp3(vb0, vb1, h, m, l);
+        if (DBG & 256) { vsb[0] = h; vsb[1] = m; vsb[2] = l; return; }      // ablation: no LDS round trip
         vpark[t_] = h; vpark[WNT + t_] = m; vpark[2 * WNT + t_] = l;
       };
       auto fetch_b = [&]() {
         int t_ = tid;
         asm volatile("" : "+v"(t_));
+        if (DBG & 256) return;
         vsb[0] = vpark[t_]; vsb[1] = vpark[WNT + t_]; vsb[2] = vpark[2 * WNT + t_];
       };
       park_b();
+#if !defined(SR3_SPLIT_ROT) || SR3_SPLIT_ROT == 1
+      const bool late = wave >= 4;                    // (waves w and w + 4 share SIMD w & 3)
+#elif SR3_SPLIT_ROT == 2
+      const bool late = (wave & 1) != 0;
+#else
+      const bool late = false;
+#endif
       for (int i = 0; i < nck; ++i) {
         float* rcur = (i & 1) ? raw1 : raw0;
         const float* rnext = (i & 1) ? raw0 : raw1;
         const bool more = i + 1 < nck;
         f32x4 da[3], db[3];
         mfma_split(0, 0, vsa);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         t_load(rcur, 1, 0, da, db);
         t_finish(da, db, va0, vb0);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         fetch_b();
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         mfma_split(0, 1, vsb);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         t_load(rcur, 1, 1, da, db);
         t_finish(da, db, va1, vb1);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         park_b();
-        __builtin_amdgcn_sched_barrier(0);
-        split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+        SR3_SB();
+        sp3(va0, va1, vsa[0], vsa[1], vsa[2]);
+        // The two waves of a SIMD run this loop in lock step (same code, one barrier per chunk), so left alone both sit in their
+        // MFMA groups together and in their transform / split sections together, and neither the matrix pipe nor the VALU is
+        // ever busy while the other is.  `late` waves (one of each SIMD's pair) issue group (m1, a) BEFORE the barrier, the others
+        // after it: from then on one wave of the pair is in an MFMA group while the other is in a VALU section.
+        SR3_SB();
+        if (late) {
+          mfma_split(1, 0, vsa);
+          if (more) load_us(c_begin + i + 1, 0);
+        }
+        SR3_SB();
         __syncthreads();
-        if (i + 2 < nck) {
+#ifdef SR3_SPLIT_SKEW
+        if (wave >= 4) __builtin_amdgcn_s_sleep(SR3_SPLIT_SKEW);      // (64 cycles per unit) de-phase the two waves of a SIMD
+#endif
+        if (i + 2 < nck && !(DBG & 32)) {
+          fetch_items();
           store_raw(rcur, c_begin + i + 2, rh, cs_);
           if (i + 3 < nck) load_raw(c_begin + i + 3, rh);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_split(1, 0, vsa);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
+        if (!late) {
+          mfma_split(1, 0, vsa);
+          if (more) load_us(c_begin + i + 1, 0);
+        }
+        SR3_SB();
         if (more) {
-          load_us(c_begin + i + 1, 0);
           t_load(rnext, 0, 0, da, db);
           t_finish(da, db, va0, vb0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         fetch_b();
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         mfma_split(1, 1, vsb);
-        __builtin_amdgcn_sched_barrier(0);
+        SR3_SB();
         if (more) {
           load_us(c_begin + i + 1, 1);
           t_load(rnext, 0, 1, da, db);
           t_finish(da, db, va1, vb1);
-          __builtin_amdgcn_sched_barrier(0);
+          SR3_SB();
           park_b();
-          __builtin_amdgcn_sched_barrier(0);
-          split3x8(va0, va1, vsa[0], vsa[1], vsa[2]);
+          SR3_SB();
+          sp3(va0, va1, vsa[0], vsa[1], vsa[2]);
         }
       }
     } else {
@@ -1009,7 +1058,8 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   const long ntiles = wino_workgroups(p, g);
   const char* np = getenv("SR3_WINO_NONPERSISTENT");
   dim3 grid((unsigned)((np && np[0] == '1') ? ntiles : std::min<long>(ntiles, n_cu > 0 ? n_cu : 256)), p.ksplit);
-  static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
+  static const int dbg_env = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
+  const int dbg = (g.NB != 1 || p.drop_thresh != 0) ? 0 : dbg_env;       // (the ablations cover the one-image tile without dropout)
 #define SR3_WINO_LAUNCH4(D, DR, N4, SP)                                                                               \
   {                                                                                                                   \
     static std::atomic<uint64_t> done{0};                                                                             \
@@ -1023,7 +1073,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
-  if (p.wino_split && (p.drop_thresh != 0 || dbg != 0 || g.NB != 1)) {
+  if (p.wino_split && (p.drop_thresh != 0 || g.NB != 1)) {
     set_error("conv: the split-bf16 Winograd kernel covers the one-image tile without dropout only");
     return SR3_E_UNSUPPORTED;
   }
@@ -1033,16 +1083,22 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
       else if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
       break;
 #ifdef SR3_WINO_ABLATIONS
-    case 1: { SR3_WINO_LAUNCH(1) } break;
+    case 1: if (p.wino_split) { SR3_WINO_LAUNCH4(1, false, false, true) } else { SR3_WINO_LAUNCH(1) } break;
     case 2: { SR3_WINO_LAUNCH(2) } break;
-    case 4: { SR3_WINO_LAUNCH(4) } break;
-    case 8: { SR3_WINO_LAUNCH(8) } break;
-    case 16: { SR3_WINO_LAUNCH(16) } break;
-    case 32: { SR3_WINO_LAUNCH(32) } break;
+    case 4: if (p.wino_split) { SR3_WINO_LAUNCH4(4, false, false, true) } else { SR3_WINO_LAUNCH(4) } break;
+    case 8: if (p.wino_split) { SR3_WINO_LAUNCH4(8, false, false, true) } else { SR3_WINO_LAUNCH(8) } break;
+    case 16: if (p.wino_split) { SR3_WINO_LAUNCH4(16, false, false, true) } else { SR3_WINO_LAUNCH(16) } break;
+    case 32: if (p.wino_split) { SR3_WINO_LAUNCH4(32, false, false, true) } else { SR3_WINO_LAUNCH(32) } break;
     case 38: { SR3_WINO_LAUNCH(38) } break;       // MFMA + U + epilogue only
     case 46: { SR3_WINO_LAUNCH(46) } break;       // MFMA + U only
     case 62: { SR3_WINO_LAUNCH(62) } break;       // bare MFMA loop
     case 64: { SR3_WINO_LAUNCH(64) } break;       // phase time stamps
+#define SR3_WINO_SPLIT_CASE(D) case D: if (p.wino_split) { SR3_WINO_LAUNCH4(D, false, false, true) } else { SR3_WINO_LAUNCH(D) } break;
+    SR3_WINO_SPLIT_CASE(128)                      // SPLIT: no residual arithmetic in the 3 x bf16 split
+    SR3_WINO_SPLIT_CASE(256)                      // SPLIT: position b's planes stay in registers (no LDS round trip)
+    SR3_WINO_SPLIT_CASE(444)                      // SPLIT: bare MFMA loop + epilogue (4 + 16 + 32 + 128 + 256)
+    SR3_WINO_SPLIT_CASE(452)                      // SPLIT: bare MFMA loop, no epilogue
+    SR3_WINO_SPLIT_CASE(445)                      // SPLIT: nothing but the prologue / epilogue
 #endif
     default: set_error("conv: SR3_WINO_DBG=%d is not built (compile with -DSR3_WINO_ABLATIONS)", dbg); return SR3_E_BADARG;
   }

@@ -87,9 +87,10 @@ def test_c2_batch16_forward_and_graph_step():
     B = 16
     netG, sd, desc, opt, c = _build('sr3_16_128')
     cfgs = _cfgs(netG, B)
-    # the bench plan: Winograd F(2x2,3x3) kernel (tile 11) on every 3x3 stride-1 layer: unsplit at 128^2 .. 32^2, split-K 2 at
-    # 16^2, the four-image tile with split-K 8 on the 8^2 layers (round 4; the direct halo kernel is gone from this plan)
-    assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(5 <= t <= 10 for t, _ in cfgs), sorted(set(cfgs))
+    # the bench plan: Winograd F(2x2,3x3) kernel on every 3x3 stride-1 layer: its 3 x bf16 split instantiation (tile 12) unsplit
+    # at 128^2 .. 32^2 and split-K 2 at 16^2, the four-image fp32 tile (11) with split-K 8 on the 8^2 layers (round 4; the
+    # direct halo kernel is gone from this plan)
+    assert (12, 1) in cfgs and (12, 2) in cfgs and (11, 8) in cfgs and not any(5 <= t <= 10 for t, _ in cfgs), sorted(set(cfgs))
     d = G.dev()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, 6, 128, 128, generator=g)
@@ -111,11 +112,11 @@ def test_c2_batch16_forward_and_graph_step():
     netG.denoise_fn.plan.set_option('winograd', 1)
 
 
-def test_c2_batch16_wino_split_option():
-    """Gate of the opt-in `wino_split` plan option at the headline configuration: the Winograd convs of maps >= 16x16 on the
-    kernel's 3 x bf16 split instantiation (tile 12).  Same stated tolerance as the exact-fp32 plan for the forward and for one
-    replay of the production graph, and the forward's error against the CPU oracle must not exceed 1.5x the exact-fp32 plan's
-    on the same input (both are printed)."""
+def test_c2_batch16_wino_split_gate_and_exact_fp32_plan():
+    """Gate of the `wino_split` plan option (default on) at the headline configuration: the Winograd convs of maps >= 16x16
+    on the kernel's 3 x bf16 split instantiation (tile 12).  Same stated tolerance as the exact-fp32 plan (`wino_split = 0`,
+    every Winograd conv on v_mfma_f32_32x32x2_f32) for the forward and for one replay of the production graph -- both plans
+    are run -- and the forward's error against the CPU oracle must not exceed 1.5x the exact-fp32 plan's on the same input."""
     from oracle import sr3_oracle as O
     B = 16
     netG, sd, desc, opt, c = _build('sr3_16_128')
@@ -125,7 +126,11 @@ def test_c2_batch16_wino_split_option():
     lvl = torch.linspace(0.05, 0.999, B).view(B, 1)
     with torch.no_grad():
         ref = O.unet_forward(sd, desc, x, lvl)
+    netG.denoise_fn.plan.set_option('wino_split', 0)
+    cfgs = _cfgs(netG, B)
+    assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(t == 12 for t, _ in cfgs), sorted(set(cfgs))
     e_fp32 = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (fp32 Winograd)')
+    _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2 exact fp32 (wino_split = 0)')
     netG.denoise_fn.plan.set_option('wino_split', 1)
     cfgs = _cfgs(netG, B)
     assert (12, 1) in cfgs and (12, 2) in cfgs and (11, 8) in cfgs and not any(t == 11 and k < 8 for t, k in cfgs), sorted(set(cfgs))
@@ -134,14 +139,13 @@ def test_c2_batch16_wino_split_option():
           % (e_fp32, e_split, ref.abs().max().item()))
     assert e_split <= 1.5 * e_fp32 + 2e-7, (e_split, e_fp32)
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2 wino_split')
-    netG.denoise_fn.plan.set_option('wino_split', 0)
 
 
 def test_c4_batch4_graph_step():
     B = 4
     netG, sd, desc, opt, c = _build('sr3_64_512')
     cfgs = _cfgs(netG, B)
-    assert any(t == 11 for t, _ in cfgs), sorted(set(cfgs))
+    assert any(t == 12 for t, _ in cfgs), sorted(set(cfgs))
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 777, 'C4')
 
 

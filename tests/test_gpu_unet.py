@@ -72,20 +72,24 @@ def test_unet_forward_split_bf16_option(name):
 
 
 @pytest.mark.parametrize('name', NAMES)
-def test_unet_forward_wino_split_option(name):
-    """Opt-in `wino_split` plan option (the Winograd kernel's 3 x bf16 split instantiation) on the reference-generated
-    vectors: same stated tolerance; toggling it back restores the exact-fp32 result bit for bit."""
+def test_unet_forward_exact_fp32_option(name):
+    """Plan option `wino_split` (default 1: the Winograd kernel's 3 x bf16 split instantiation) switched off -- every Winograd
+    conv on the fp32 MFMA -- on the reference-generated vectors: same stated tolerance; toggling it back restores the default
+    plan's result bit for bit."""
     m, g, sd = build(name)
     un = m.netG.denoise_fn
     d = G.dev()
     x, t = torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d)
-    e0 = un(x, t).clone()
-    un.plan.set_option('wino_split', 1)
+    assert un.plan.options.get('wino_split', 1) == 1
     has12 = any(o['tile_cfg'] == 12 for o in un.plan.op_list(x.shape[0]))
-    e1 = un(x, t).clone()
-    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (wino_split)')
-    assert has12 == (not torch.equal(e0, e1)) or not has12
+    e0 = un(x, t).clone()
+    G.assert_close(e0.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (default plan)')
     un.plan.set_option('wino_split', 0)
+    assert not any(o['tile_cfg'] == 12 for o in un.plan.op_list(x.shape[0]))
+    e1 = un(x, t).clone()
+    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (wino_split = 0)')
+    assert has12 or torch.equal(e0, e1)
+    un.plan.set_option('wino_split', 1)
     assert torch.equal(un(x, t), e0)
 
 
@@ -252,7 +256,7 @@ def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
     t = torch.from_numpy(g['unet/time']).to(d)
     ref = torch.from_numpy(g['unet/eps'])
     G.assert_close(un(x, t).cpu(), ref, what='before')
-    assert any(o['tile_cfg'] == 11 for o in un.plan.op_list(x.shape[0])), 'the plan has no Winograd op: nothing derived to test'
+    assert any(o['tile_cfg'] in (11, 12) for o in un.plan.op_list(x.shape[0])), 'the plan has no Winograd op: nothing derived to test'
     # (1) raw C-ABI call after an invalidation: loud failure; after prepare: fine again
     lib = un.plan.lib
     L.check(lib.sr3_plan_invalidate_derived(un.plan.handle))
@@ -271,7 +275,7 @@ def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
     G.assert_close(un(x, t).cpu(), ref, what='after weights_changed')
     # (2) option toggle after a forward
     un.plan.set_option('winograd', 0)
-    assert not any(o['tile_cfg'] == 11 for o in un.plan.op_list(x.shape[0]))
+    assert not any(o['tile_cfg'] in (11, 12) for o in un.plan.op_list(x.shape[0]))
     G.assert_close(un(x, t).cpu(), ref, what='winograd off')
     un.plan.set_option('winograd', 1)
     G.assert_close(un(x, t).cpu(), ref, what='winograd on again')

@@ -29,6 +29,9 @@ def child(cfg_name, reps):
     un = netG.denoise_fn
     plan = un.plan
     plan.set_option('fuse_stats', 1)
+    for kv in os.environ.get('SR3_ABLATE_OPTS', '').split(','):
+        if kv:
+            plan.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     un.ensure_derived()
     B, S = cfg['batch'], cfg['size']
     x = torch.randn(B, 3, S, S, device=dev)
@@ -79,12 +82,14 @@ def main():
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--child', action='store_true')
     ap.add_argument('--tag', default='wino_ablate')
+    ap.add_argument('--opt', default='', help='plan options for the child, e.g. wino_split=1')
+    ap.add_argument('--kind', type=int, default=455, help='profile kind to tabulate (455 fp32 Winograd, 555 its 3 x bf16 split form)')
     a = ap.parse_args()
     if a.child:
         return child(a.config, a.reps)
     res = {}
     for d in [int(v) for v in a.dbg.split(',')]:
-        env = dict(os.environ, SR3_WINO_DBG=str(d))
+        env = dict(os.environ, SR3_WINO_DBG=str(d), SR3_ABLATE_OPTS=a.opt)
         if a.lib:
             env['SR3_LIBRARY'] = a.lib
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', '--config', a.config, '--reps', str(a.reps)],
@@ -103,7 +108,7 @@ def main():
     base = res[0]['rows']
     groups = {}
     for i, (k, ms, fl, label) in enumerate(base):
-        if k == 455:
+        if k == a.kind:
             groups.setdefault(label, []).append(i)
     ds = sorted(res)
     print('us per launch      %-26s %3s %6s ' % ('layer', 'n', 'GFLOP') + ' '.join('%7s' % ('dbg%d' % d) for d in ds))
@@ -113,7 +118,7 @@ def main():
             rows = res[d]['rows']
             cells.append('%7.1f' % (1e3 * sum(rows[i][1] for i in idx) / len(idx)))
         print('                   %-26s %3d %6.2f ' % (label, len(idx), base[idx[0]][2] / 1e9) + ' '.join(cells))
-    print('%-56s' % 'Winograd launches, ms per forward' + ' '.join('%7.3f' % sum(r[1] for r in res[d]['rows'] if r[0] == 455) for d in ds))
+    print('%-56s' % 'Winograd launches, ms per forward' + ' '.join('%7.3f' % sum(r[1] for r in res[d]['rows'] if r[0] == a.kind) for d in ds))
     print('%-56s' % 'forward, ms' + ' '.join('%7.3f' % res[d]['total_ms'] for d in ds))
 
 
