@@ -1073,13 +1073,14 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
-  if (p.wino_split && (p.drop_thresh != 0 || g.NB != 1)) {
-    set_error("conv: the split-bf16 Winograd kernel covers the one-image tile without dropout only");
+  if (p.wino_split && g.NB != 1) {
+    set_error("conv: the split-bf16 Winograd kernel covers the one-image tile only");
     return SR3_E_UNSUPPORTED;
   }
   switch (dbg) {
     case 0:
-      if (p.wino_split) { SR3_WINO_LAUNCH4(0, false, false, true) }
+      if (p.wino_split && p.drop_thresh != 0) { SR3_WINO_LAUNCH4(0, true, false, true) }
+      else if (p.wino_split) { SR3_WINO_LAUNCH4(0, false, false, true) }
       else if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
       break;
 #ifdef SR3_WINO_ABLATIONS

@@ -392,10 +392,10 @@ struct Builder {
     if (wino_ok(c, w, q0 >= 0, o.has_drop)) {
       o.tile_cfg = 11;
       o.wino_off = P->derived_of[w];
-      // plan option wino_split: the 3 x bf16 split instantiation where it exists (inference, one-image tile, no dropout); its
-      // filters sit behind the conv's fp32 ones
+      // plan option wino_split: the 3 x bf16 split instantiation where it exists (the one-image tile; training plan and
+      // train-mode dropout included); its filters sit behind the conv's fp32 ones
       WinoGeom wg;
-      if (P->wino_split && !train && !o.has_drop && wino_geometry(c, &wg) && wg.NB == 1) {
+      if (P->wino_split && wino_geometry(c, &wg) && wg.NB == 1) {
         c.wino_split = 1;
         o.wino_off += wino_weight_floats(Cout, C0 + C1);
       }
@@ -795,7 +795,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
         WinoGeom wg;
         if (P->winograd && r.ksize == 3 && wino_geometry(g, &wg)) {
           max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 11, 0));
-          max_wu = std::max(max_wu, wino_weight_floats(g.Cout, g.C0) * sizeof(float));
+          max_wu = std::max(max_wu, wino_weight_floats(g.Cout, g.C0, P->wino_split && wg.NB == 1) * sizeof(float));
         }
       }
       if (r.has_q) {
@@ -1209,13 +1209,15 @@ int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cou
   // same mapping p -> (threshold, scale) as sr3_train_step
   c.drop_seed = drop_seed;
   dropout_consts(drop_p, &c.drop_thresh, &c.drop_scale);
+  const bool wsplit = tile_cfg == 12;         // 12 = tile 11 on the 3 x bf16 split instantiation
+  if (wsplit) { tile_cfg = 11; c.wino_split = 1; }
   if (tile_cfg == 11) {       // Winograd form: the transformed filters are derived here, behind the split-K slabs (as sr3_conv_f32)
     if (c.x2_w) { set_error("conv: the Winograd kernel has no fused 1x1 segment"); return SR3_E_UNSUPPORTED; }
     const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
-    const size_t ub = wino_weight_floats(Cout, C0) * sizeof(float);
+    const size_t ub = wino_weight_floats(Cout, C0, wsplit) * sizeof(float);
     if (!scratch || scratch_bytes < slab + ub) { set_error("conv: Winograd scratch too small (%zu < %zu)", scratch_bytes, slab + ub); return SR3_E_NOMEM; }
     float* u = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
-    const int rc = wino_transform_weights(w, Cout, C0, u, static_cast<hipStream_t>(stream));
+    const int rc = wino_transform_weights(w, Cout, C0, u, static_cast<hipStream_t>(stream), wsplit);
     if (rc) return rc;
     c.wino_u = u;
     scratch_bytes = slab;

@@ -44,10 +44,12 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   // 3x3: Winograd F(2x2,3x3) on the flipped-transposed filters where the geometry fits (the data gradient has neither a
   // prologue nor dropout, so every 3x3 stride-1 / zero-inserted stride-2 layer with H, W multiples of 16 qualifies)
   WinoGeom wg;
+  const bool split = X.P->wino_split != 0;            // (the one-image tile: the 3 x bf16 split instantiation, as the forward)
   if (X.P->winograd && ksize == 3 && wino_geometry(c, &wg) &&
-      wino_weight_floats(Cin, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
+      wino_weight_floats(Cin, Cg, split && wg.NB == 1) * sizeof(float) <= X.P->t_wu_bytes) {
     float* wu = X.at<float>(X.P->t_wu_off);
-    rc = wino_transform_weights(wt, Cin, Cg, wu, X.st);
+    c.wino_split = (split && wg.NB == 1) ? 1 : 0;
+    rc = wino_transform_weights(wt, Cin, Cg, wu, X.st, c.wino_split != 0);
     if (rc) return rc;
     c.wino_u = wu;
     return conv_forward(c, 11, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);

@@ -91,8 +91,14 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "loss_l2"};
+ * "wino_split", "loss_l2"};
  * returns previous value.
+ * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
+ *   split instantiation: every fp32 operand as x = h + m + l (three bf16 terms, each residual exact in fp32), every product as
+ *   the six bf16 MFMA products hh, hm, mh, mm, hl, lh with fp32 accumulation (v_mfma_f32_32x32x16_bf16) -- fp32-class results
+ *   (dropped terms <= 2^-24 of a product; measured not less accurate than the fp32-MFMA instantiation on every layer shape,
+ *   tests/test_gpu_ops.py), not the bit pattern of the fp32 MFMA.  The derived buffer then holds both forms of every filter
+ *   (sr3_plan_derived_bytes grows 2.5x; re-bind after toggling).  0: v_mfma_f32_32x32x2_f32 everywhere.
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
  * split_bf16 (default 0, experimental): run the halo-tile 3x3 convolutions of the inference plan on
@@ -116,7 +122,8 @@ int sr3_plan_tap_info(sr3_plan* plan, int index, char* name, int name_len, size_
  * optimizer step): ~55 small launches.
  * STALE FILTERS FAIL LOUDLY: sr3_unet_forward / sr3_train_step return SR3_E_BADARG when the plan needs the filters and
  * (a) none is bound, (b) the buffer was never prepared, (c) it was prepared from a different `params` pointer than the
- * call's, (d) the plan options that decide its content changed since, or (e) sr3_plan_invalidate_derived was called
+ * call's, (d) one of the plan options winograd / tile_cfg / split_bf16 / wino_split was set since (wino_split also changes
+ * sr3_plan_derived_bytes and un-binds a buffer that is now too small), or (e) sr3_plan_invalidate_derived was called
  * after the last prepare.  The library cannot see writes to the arena (sr3_adam_step takes no plan): a caller that
  * updates parameters in place calls sr3_plan_invalidate_derived right after the update and prepares again before the
  * next forward. */
@@ -218,7 +225,9 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * ksize 1|3 (pad ksize/2), prologue act 0 none | 1 x*scale+shift | 2 silu(x*scale+shift) with
  * ss[B][Cin][2]; epilogue + bias + film[b*film_stride+n] + residual (res0|res1 concat view).
  * weights OHWI.  tile_cfg/ksplit 0 = auto (direct kernels only); tile_cfg 11 = Winograd F(2x2,3x3) (3x3 stride 1, H and W
- * multiples of 16 or 8x8 maps; the transformed filters are derived into `scratch` by this entry point).
+ * multiples of 16, or 8x8 maps with B % 4 == 0 -- four images per workgroup tile, split-K only; the transformed filters are
+ * derived into `scratch` by this entry point); tile_cfg 12 = the same kernel's 3 x bf16 split instantiation (one-image tile
+ * only; what plan option wino_split selects).
  * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11), sized by sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
                  int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,
@@ -237,7 +246,8 @@ int sr3_block_conv_f32(const float* src0, int C0, const float* src1, int C1, int
  *   [+ residual res0] [+ conv1x1(x2_src0|x2_src1) + x2_bias], the op sr3_train_step launches for every block2.
  * Mask: NHWC element i of the activated input is kept iff hash32(i * 0x9E3779B9 + drop_seed) >= drop_p * 2^32 and
  * scaled by 1 / (1 - drop_p) (drop_seed is the per-layer seed).  Single source, no upsampling; x2_* may be NULL.
- * tile_cfg 11 runs the Winograd kernel's dropout instantiation (what sr3_train_step uses on maps >= 16x16; no x2 segment:
+ * tile_cfg 11 / 12 run the Winograd kernel's dropout instantiations (fp32 MFMA / 3 x bf16 split; what sr3_train_step uses on
+ * maps >= 16x16 with wino_split = 0 / 1; no x2 segment:
  * scratch then also holds the transformed filters, as for sr3_conv_f32 -- sr3_conv_scratch_bytes accounts for them). */
 int sr3_conv_dropout_f32(const float* src0, int C0, int B, int H, int W, int Cout, const float* w_ohwi,
                          const float* bias, const float* ss, int act, const float* film, int film_stride,

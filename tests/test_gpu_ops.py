@@ -36,6 +36,10 @@ DROP_CASES = [
     ('wino_splitk', 2, 128, 16, 16, 64, 0, 0, True, 11, 2),
     ('wino_c3_64sq_128to128', 1, 128, 64, 64, 128, 0, 0, True, 11, 1),
     ('wino_c3_128sq_64to64', 1, 64, 128, 128, 64, 0, 0, False, 11, 1),
+    # round 4: the dropout form of the 3 x bf16 split instantiation (tile 12: what the training plan's block2 convs run)
+    ('wino_split_16x16', 2, 64, 16, 16, 128, 0, 0, True, 12, 1),
+    ('wino_split_splitk', 2, 128, 16, 16, 64, 0, 0, True, 12, 2),
+    ('wino_split_c3_64sq_128to128', 1, 128, 64, 64, 128, 0, 0, True, 12, 1),
     # round 4: the four-image tile of the 8x8 maps (split-K only)
     ('wino_8x8_b4', 4, 128, 8, 8, 128, 0, 0, True, 11, 2),
     ('wino_8x8_b8_512', 8, 512, 8, 8, 64, 0, 0, False, 11, 0),
