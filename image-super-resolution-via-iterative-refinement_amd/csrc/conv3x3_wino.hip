@@ -1073,6 +1073,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
+  if (p.wino_split == 2 && g.NB == 1 && p.drop_thresh == 0) return conv3x3_wino4_forward(p, g, ufrag, st);
   if (p.wino_split && g.NB != 1) {
     set_error("conv: the split-bf16 Winograd kernel covers the one-image tile only");
     return SR3_E_UNSUPPORTED;

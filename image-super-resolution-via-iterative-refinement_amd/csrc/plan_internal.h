@@ -103,6 +103,7 @@ struct sr3_plan {
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
                              // 68 TF vs 72 TF for the im2col kernel's 64x64 tile on this network's layers, so off by default
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
+  int wino4 = 0;             // wino_split convs on the four-wave, 512-register kernel (conv3x3_wino4.hip) where it applies
   int wino_split = 1;        // ... on its 3 x bf16 split instantiation (bf16 MFMA, fp32-class results; gated by tests/: error not
                              // above the fp32-MFMA instantiation's on every layer shape, 2000-step drift) where that exists: the
                              // one-image tile of the inference plan.  0: the exact-fp32 MFMA instantiation everywhere

@@ -110,7 +110,8 @@ struct ConvParams {
   float drop_scale;
   // tile_cfg 11 (Winograd): this conv's transformed filters in fragment-major order (conv3x3_wino.hip)
   const float* wino_u;
-  int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI)
+  int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI);
+                       // 2: the same filters on the four-wave kernel of conv3x3_wino4.hip (tile_cfg 13)
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -169,6 +170,8 @@ int wino_chunks(const ConvParams& p);
 size_t wino_weight_floats(int Cout, int Cin, bool split = false);
 int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st, bool split = false);
 int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st);
+// the 3 x bf16 split form on four 512-register waves (conv3x3_wino4.hip; ConvParams::wino_split == 2, tile_cfg 13 at the ABI)
+int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* ufrag, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
 // partial per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]:

@@ -161,7 +161,7 @@ def test_conv(case, tile_cfg, ksplit):
 
 
 @pytest.mark.parametrize('ksplit', [1, 2])
-@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6, 9, 10, 11])
+@pytest.mark.parametrize('tile_cfg', [0, 3, 5, 6, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize('case', [('stats8', 3, 64, 0, 8, 8, 96, 3, 1, 0, 2, True, True, True),
                                   ('stats32', 2, 32, 32, 32, 32, 160, 3, 1, 0, 2, True, True, True),
                                   ('stats_up', 2, 32, 0, 16, 16, 64, 3, 1, 1, 0, False, False, True)],
@@ -214,7 +214,7 @@ STRESS_CASES = [
 ]
 
 
-@pytest.mark.parametrize('tile', [11, 12], ids=['fp32', 'split'])
+@pytest.mark.parametrize('tile', [11, 12, 13], ids=['fp32', 'split', 'split4w'])
 @pytest.mark.parametrize('ksplit', [0, 1])
 @pytest.mark.parametrize('case', STRESS_CASES, ids=[c[0] for c in STRESS_CASES])
 def test_winograd_conv_stress_absolute_bound(case, ksplit, tile):
@@ -286,9 +286,10 @@ def test_winograd_conv_error_is_fp32_class(case, ksplit):
 SPLIT_GATE_CASES = [c for c in WINO_CASES if c[4] >= 16]          # (the four-image 8x8 tile has no split instantiation)
 
 
+@pytest.mark.parametrize('tile', [12, 13], ids=['8wave', '4wave'])
 @pytest.mark.parametrize('ksplit', [0, 1, 2])
 @pytest.mark.parametrize('case', SPLIT_GATE_CASES, ids=[c[0] for c in SPLIT_GATE_CASES])
-def test_winograd_split_error_not_above_fp32_winograd(case, ksplit):
+def test_winograd_split_error_not_above_fp32_winograd(case, ksplit, tile):
     """Gate of the `wino_split` plan option (tile 12: the Winograd kernel's 3 x bf16 split instantiation -- every fp32 operand
     as h + m + l, six bf16 MFMA products per term, fp32 accumulation): on every layer shape of the BASELINE networks its error
     against float64 must not exceed the exact-fp32 Winograd kernel's (tile 11) on the same data -- rms within 5 %, max within
@@ -296,7 +297,7 @@ def test_winograd_split_error_not_above_fp32_winograd(case, ksplit):
     src0, src1, w, kw = _make_case(case, seed=7)
     ref = G.conv_ref(src0, src1, w, **kw)
     try:
-        got, _ = G.conv_call(src0, src1, w, tile_cfg=12, ksplit=ksplit, **kw)
+        got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
         base, _ = G.conv_call(src0, src1, w, tile_cfg=11, ksplit=ksplit, **kw)
     except L.Sr3Error as e:
         if 'empty split' in str(e):
@@ -307,8 +308,8 @@ def test_winograd_split_error_not_above_fp32_winograd(case, ksplit):
     e_w = G.assert_close(base, ref, what=case[0] + ' (Winograd, fp32 MFMA)')
     rms_s = (got.double() - ref).pow(2).mean().sqrt().item()
     rms_w = (base.double() - ref).pow(2).mean().sqrt().item()
-    print('%s ks%d: max/rms err split %.2e/%.2e  fp32 Winograd %.2e/%.2e  |ref|max %.2f'
-          % (case[0], ksplit, e_s, rms_s, e_w, rms_w, ref.abs().max().item()))
+    print('%s ks%d tile %d: max/rms err split %.2e/%.2e  fp32 Winograd %.2e/%.2e  |ref|max %.2f'
+          % (case[0], ksplit, tile, e_s, rms_s, e_w, rms_w, ref.abs().max().item()))
     assert rms_s <= 1.05 * rms_w, (rms_s, rms_w)
     assert e_s <= 1.25 * e_w + 1e-8 * ref.abs().max().item(), (e_s, e_w)
 

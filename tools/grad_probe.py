@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, 'image-super-resolution-via-iterative-refinem
     sys.path.insert(0, p)
 import torch                                      # noqa: E402
 
-DEFAULTS = dict(winograd=1, ksplit=0, fuse_stats=1, fuse_res=1, tile_cfg=0)
+DEFAULTS = dict(winograd=1, wino_split=1, ksplit=0, fuse_stats=1, fuse_res=1, tile_cfg=0)
 
 
 def gammas(mode, B, g):
