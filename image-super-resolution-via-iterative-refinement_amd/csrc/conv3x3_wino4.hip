@@ -41,7 +41,8 @@ constexpr int QEXCH_F = 4 * 2 * QEPL;                 // 4 waves x 2 (q) planes
 constexpr int QTAB_F = 2 * QHI * QNT;                 // parked staging items: [item][thread] of (hinfo, pixel)
 constexpr int Q_MAX_CK = 64;
 constexpr int QCST_F = 64 + Q_MAX_CK * 2 * QCK;
-static_assert(2 * QRAW_F + QTAB_F <= QEXCH_F, "raw tiles + item table inside the exchange block's footprint");
+constexpr int QDUMMY_F = QNT * 4;                     // one 16-byte slot per thread: where a switched-off staging write lands
+static_assert(2 * QRAW_F + QTAB_F + QDUMMY_F <= QEXCH_F, "raw tiles + item table + dummy slots inside the exchange block's footprint");
 constexpr int Q_SMEM = (QEXCH_F + 2 * QCST_F) * 4;    // 71,680 + 16,896 bytes
 constexpr int QUS = 3 * 64 * 8;  // bf16 elements of one (position, n block) fragment group (conv3x3_wino.hip: WUS)
 
@@ -132,8 +133,9 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
       hinfo_r[j] = v.x; hpix[j] = v.y;
     }
   };
-  f32x4 rh[QHI];
-  auto load_raw = [&](int chunk) {
+  f32x4 rh[QHI];            // staging registers of the main loop (and of a tile's chunk 0)
+  f32x4 rh2[QHI];           // ... of a tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
+  auto load_raw = [&](int chunk, f32x4 (&rh)[QHI]) {
     const int c = chunk * QCK + kq * 4;
     const int ce = c < Cin ? c : 0;
     const bool second = ce >= p.C0;
@@ -146,7 +148,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
       rh[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
     }
   };
-  auto store_raw = [&](float* raw, int chunk, const float* cs_) {
+  auto store_raw = [&](float* raw, int chunk, const f32x4 (&rh)[QHI], const float* cs_) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool hvalid = chunk * QCK + kq * 4 < Cin;
     f32x4 ssa = zero, ssb = zero;
@@ -169,6 +171,45 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
         v = (hvalid && hpix[j] >= 0) ? v : zero;
         *reinterpret_cast<f32x4*>(&raw[hinfo_r[j] + kq * 4]) = v;
       }
+    }
+  };
+  // Main-loop form of the staging step, in two halves (items 3 h .. 3 h + 2) and WITHOUT branches, so that it can sit inside
+  // an MFMA group's scheduling region and run in the gaps of the MFMA stream: `on` (wave-uniform: there is a chunk to stage)
+  // only selects the LDS address -- a switched-off write lands in the thread's dummy slot -- and the chunk of the next global
+  // load is clamped by the caller.  Items are re-read from their LDS table, the (scale, shift) pairs from the constants block.
+  float* dummy_slot = smem + 2 * QRAW_F + QTAB_F + tid * 4;
+  auto stage_half = [&](int h, float* raw, bool on, int chunk, int next_chunk, const float* cs_) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool hvalid = chunk * QCK + kq * 4 < Cin;
+    f32x4 ssa = zero, ssb = zero;
+    if (p.act != 0) {
+      const float* q = cs_ + 64 + (chunk - c_begin) * (2 * QCK) + kq * 8;
+      ssa = *reinterpret_cast<const f32x4*>(q);
+      ssb = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+    const int cnx = next_chunk * QCK + kq * 4;
+    const int ce = cnx < Cin ? cnx : 0;
+    const bool second = ce >= p.C0;
+    const float* sp_ = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int j = 3 * h + jj;
+      const qint2 it = reinterpret_cast<const qint2*>(ptab)[j * QNT + tid];      // (LDS offset | -1, source pixel | -1)
+      f32x4 v = rh[j];
+      if (p.act != 0) {
+        v.x = fmaf(v.x, ssa.x, ssa.y);
+        v.y = fmaf(v.y, ssa.z, ssa.w);
+        v.z = fmaf(v.z, ssb.x, ssb.y);
+        v.w = fmaf(v.w, ssb.z, ssb.w);
+        if (p.act == 2) { v.x = silu_q(v.x); v.y = silu_q(v.y); v.z = silu_q(v.z); v.w = silu_q(v.w); }
+      }
+      v = (hvalid && it.y >= 0) ? v : zero;
+      float* dstp = (on && it.x >= 0) ? raw + it.x + kq * 4 : dummy_slot;
+      *reinterpret_cast<f32x4*>(dstp) = v;
+      const int off = it.y >= 0 ? it.y * sC + cs : 0;
+      rh[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
     }
   };
   // per-tile constants: bias + FiLM row of the 64 output channels (cst[0..63]), (scale, shift) pairs of the split's channels
@@ -205,6 +246,11 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
   const int offb = (r0 + rb) * QROW + (((r0 + rb) >> 1) & 1) * QSHIFT + (2 * tx) * QRS + hq * 4;
   // row pass of one half unit (tile block m, half chunk kk): eight reads, four patch columns
   auto rowpass = [&](const float* rawbuf, int m, int kk, f32x4 (&t)[4]) {
+    if (DBG & 4) {                // ablation: no LDS reads, no row pass
+#pragma unroll
+      for (int s = 0; s < 4; ++s) t[s] = f32x4{1.f, 2.f, 3.f, 4.f};
+      return;
+    }
     f32x4 da[4], db[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -223,6 +269,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
   qbf16x8 us[4][2][3];
   const __bf16* ubase = nullptr;
   auto load_us = [&](int chunk, int pj) {
+    if ((DBG & 16) && chunk != c_begin) return;
     const __bf16* q = ubase + (size_t)chunk * 16 * (2 * QUS) + pj * (2 * QUS);
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -234,20 +281,45 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
   // position's operands (-> `vn`) interleaved between them: one wave per SIMD, so the VALU work has to sit inside the MFMA stream
   // in program order to run beside it (sched_group_barrier: one MFMA, then up to four VALU instructions, twelve times).
   qbf16x8 vc[3], vn[3];
-  auto mfma_pos = [&](int m, int pj, bool has_next, const f32x4& nlo, const f32x4& nhi) {
+  auto mfma_pos = [&](int m, int pj, bool has_next, const f32x4& nlo, const f32x4& nhi, auto&& filler, int valu_per_mfma) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first
     __builtin_amdgcn_sched_barrier(0);
-    if (has_next) split3x8q(nlo, nhi, vn[0], vn[1], vn[2]);
+    filler();                     // independent work that shares this group's scheduling region (the staging halves)
+    if (has_next) {
+      if (DBG & 128) {            // ablation: one conversion per value instead of the 3-way split
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+        for (int e = 0; e < 8; ++e) vn[0][e] = (__bf16)(e < 4 ? nlo[e] : nhi[e - 4]);
+        vn[1] = vn[0]; vn[2] = vn[0];
+      } else {
+        split3x8q(nlo, nhi, vn[0], vn[1], vn[2]);
+      }
+    }
+    if (DBG & 1) {                // ablation: no MFMAs (operands kept live)
 #pragma unroll
       for (int n = 0; n < 2; ++n)
-        acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[PA[q]], us[pj][n][PB[q]], acc[pj][m][n], 0, 0, 0);
-#ifndef SR3_W4_NO_INTERLEAVE
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // up to four VALU
+        for (int pl = 0; pl < 3; ++pl) acc[pj][m][n][pl] += (float)vc[pl][0] * (float)us[pj][n][pl][0];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[pj][m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc[PA[q]], us[pj][n][PB[q]], acc[pj][m][n], 0, 0, 0);
+    }
+#ifndef SR3_W4_NO_INTERLEAVE
+    if (valu_per_mfma <= 4) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // up to four VALU
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);      // up to seven VALU ...
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);      // ... and two transcendentals (the staging half's SiLU)
+      }
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -260,13 +332,19 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
   const size_t Mtot = (size_t)p.B * H * W;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * Mtot * p.Cout;
 
-  for (int vtile = blockIdx.x; vtile < ntiles; vtile += gridDim.x) {
+  // Persistent workgroups: what a tile needs before its main loop -- constants, staging items, raw chunks 0 and 1 -- is fetched
+  // during the previous tile's epilogue (the last tile re-fetches itself: the loads stay unconditional).
+  int vtile = blockIdx.x;
+  int par = 0;
+  const int c1 = min(c_begin + 1, c_end - 1);
+  decode_tile(vtile);
+  set_items();
+  load_raw(c_begin, rh);
+  load_raw(c1, rh2);
+  stage_consts(cst);
+  for (;;) {
     // ================================ prologue ================================
-    decode_tile(vtile);
-    const float* cs_ = cst;
-    stage_consts(cst);
-    set_items();
-    park_items();
+    const float* cs_ = cst + par * QCST_F;
     ubase = ufrag + (size_t)cb * nch * 16 * (2 * QUS) + (size_t)(wi * 4) * (2 * QUS) + lane * 8;
 #pragma unroll
     for (int pj = 0; pj < 4; ++pj) load_us(c_begin, pj);
@@ -278,14 +356,11 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
-    load_raw(c_begin);
-    __syncthreads();                       // the constants are visible (and the previous tile's epilogue is done with LDS)
-    store_raw(raw0, c_begin, cs_);
-    if (nck > 1) {
-      load_raw(c_begin + 1);
-      store_raw(raw1, c_begin + 1, cs_);
-    }
-    if (nck > 2) load_raw(c_begin + 2);
+    __syncthreads();                       // the constants are visible, the previous tile's epilogue is done with LDS
+    park_items();
+    store_raw(raw0, c_begin, rh, cs_);
+    if (nck > 1) store_raw(raw1, c_begin + 1, rh2, cs_);
+    if (nck > 2) load_raw(c_begin + 2, rh);
     __syncthreads();
 
     // ================================ main loop ================================
@@ -300,33 +375,32 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
       const float* rnext = (i & 1) ? raw0 : raw1;
       const bool more = i + 1 < nck;
       // ---- unit (i, m0); next: (i, m1) from rcur ----
-      mfma_pos(0, 0, true, colpass(tt[0], 1), colpass(tt[1], 1));
-      mfma_pos(0, 1, true, colpass(tt[0], 2), colpass(tt[1], 2));
+      auto none = [] {};
+      mfma_pos(0, 0, true, colpass(tt[0], 1), colpass(tt[1], 1), none, 4);
+      mfma_pos(0, 1, true, colpass(tt[0], 2), colpass(tt[1], 2), none, 4);
       rowpass(rcur, 1, 0, tn[0]);
-      mfma_pos(0, 2, true, colpass(tt[0], 3), colpass(tt[1], 3));
+      mfma_pos(0, 2, true, colpass(tt[0], 3), colpass(tt[1], 3), none, 4);
       rowpass(rcur, 1, 1, tn[1]);
-      mfma_pos(0, 3, true, colpass(tn[0], 0), colpass(tn[1], 0));       // (next position = position 0 of unit m1)
+      mfma_pos(0, 3, true, colpass(tn[0], 0), colpass(tn[1], 0), none, 4);      // (next position = position 0 of unit m1)
 #pragma unroll
       for (int s = 0; s < 4; ++s) { tt[0][s] = tn[0][s]; tt[1][s] = tn[1][s]; }
       __syncthreads();                     // rcur is fully consumed: chunk i + 2 goes into it; chunk i + 1 is visible in rnext
-      if (i + 2 < nck) {
-        fetch_items();
-        store_raw(rcur, c_begin + i + 2, cs_);
-        if (i + 3 < nck) load_raw(c_begin + i + 3);
-      }
-      // ---- unit (i, m1); next: (i + 1, m0) from rnext; U of chunk i + 1 per position.  Straight-line code (the interleaving
-      // directives work on one basic block): the last chunk re-fetches its own U fragments and transforms a stale raw tile, and
-      // nothing reads the results ----
+      // ---- unit (i, m1); next: (i + 1, m0) from rnext; U of chunk i + 1 per position; chunk i + 2 is staged into rcur in the
+      // gaps of the first two MFMA groups.  Straight-line code (the interleaving directives work on one basic block): the last
+      // chunks re-fetch their own U fragments / raw data, transform a stale raw tile and stage into a dummy slot, and nothing reads
+      // the results ----
       const int cn = c_begin + (more ? i + 1 : i);
-      mfma_pos(1, 0, true, colpass(tt[0], 1), colpass(tt[1], 1));
+      const bool on = i + 2 < nck && !(DBG & 32);
+      const int cst_chunk = c_begin + min(i + 2, nck - 1), nxt_chunk = c_begin + min(i + 3, nck - 1);
+      mfma_pos(1, 0, true, colpass(tt[0], 1), colpass(tt[1], 1), [&] { if (!(DBG & 32)) stage_half(0, rcur, on, cst_chunk, nxt_chunk, cs_); }, 9);
       load_us(cn, 0);
-      mfma_pos(1, 1, true, colpass(tt[0], 2), colpass(tt[1], 2));
+      mfma_pos(1, 1, true, colpass(tt[0], 2), colpass(tt[1], 2), [&] { if (!(DBG & 32)) stage_half(1, rcur, on, cst_chunk, nxt_chunk, cs_); }, 9);
       load_us(cn, 1);
       rowpass(rnext, 0, 0, tn[0]);
-      mfma_pos(1, 2, true, colpass(tt[0], 3), colpass(tt[1], 3));
+      mfma_pos(1, 2, true, colpass(tt[0], 3), colpass(tt[1], 3), none, 4);
       load_us(cn, 2);
       rowpass(rnext, 0, 1, tn[1]);
-      mfma_pos(1, 3, true, colpass(tn[0], 0), colpass(tn[1], 0));
+      mfma_pos(1, 3, true, colpass(tn[0], 0), colpass(tn[1], 0), none, 4);
       load_us(cn, 3);
 #pragma unroll
       for (int s = 0; s < 4; ++s) { tt[0][s] = tn[0][s]; tt[1][s] = tn[1][s]; }
@@ -337,6 +411,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     // Y[p][q] = sum_i A^T[p][i] P_q(i) through LDS in a FIXED order: p = 0: (r0 + r1) + r2, p = 1: (r1 - r2) - r3.  Plane (wave i,
     // q) = [32 channels][64 tiles + 4 pad], channels >= 16 shifted by 4 floats (the layout of conv3x3_wino.hip); one 32-channel
     // block per round; thread -> (q, 4 consecutive tiles, 4 consecutive channels), both p.
+    const int e_cb = cb, e_b0 = b0, e_tix = th_i * g.tiles_w + tw_i, e_vtile = vtile;
     const int nq = lane & 7, fq = (lane >> 4) & 1;
     const int tq = ((lane >> 5) & 1) | (((lane >> 3) & 1) << 1) | (wave << 2);      // tiles 4 tq .. 4 tq + 3 (half a tile row)
     const int ety = tq >> 1, etx0 = (tq & 1) * 4;
@@ -344,6 +419,47 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     f32x4 base[2];
 #pragma unroll
     for (int nblk = 0; nblk < 2; ++nblk) base[nblk] = *reinterpret_cast<const f32x4*>(cs_ + nblk * 32 + nq * 4);
+    // this tile's residual, both rounds and both p: 16 loads put in flight before the exchange (absent: a valid dummy address)
+    f32x4 addv[2][2][4];
+#pragma unroll
+    for (int nblk = 0; nblk < 2; ++nblk) {
+      const int n = e_cb * QBN + nblk * 32 + nq * 4;
+      const int ne = n < p.Cout ? n : 0;
+#pragma unroll
+      for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const size_t pix = pixp0 + (size_t)pp * W + 2 * k;
+          const float* rp = dst + pix * p.Cout + ne;
+          if (has_res) rp = (ne < p.RC0) ? p.res0 + pix * p.RC0 + ne : p.res1 + pix * p.RC1 + (ne - p.RC0);
+          addv[nblk][pp][k] = *reinterpret_cast<const f32x4*>(rp);
+        }
+    }
+    if (DBG & 8) {                                     // ablation: no epilogue (one store keeps the accumulators live)
+      float sacc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc += acc[a][b][c][r];
+      p.out[(size_t)e_vtile * QNT + tid] = sacc + addv[0][0][0][0];
+      const bool nxt = vtile + (int)gridDim.x < ntiles;
+      if (nxt) vtile += gridDim.x;
+      __syncthreads();
+      decode_tile(vtile);
+      set_items();
+      load_raw(c_begin, rh);
+      load_raw(c1, rh2);
+      stage_consts(cst + (par ^ 1) * QCST_F);
+      par ^= 1;
+      if (!nxt) break;
+      continue;
+    }
+    const bool has_next = vtile + (int)gridDim.x < ntiles;
+    if (has_next) vtile += gridDim.x;
     __syncthreads();                                   // the raw tiles and the item table are dead: the exchange block reuses LDS
     float* exch = smem;
     double s1[2][4], s2[2][4];
@@ -355,9 +471,8 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     float* wbase = exch + (wave * 2) * QEPL + wn * QETS + (wn >> 4) * 4 + 4 * (lane >> 5);
 #pragma unroll
     for (int nblk = 0; nblk < 2; ++nblk) {
-      const int n = cb * QBN + nblk * 32 + nq * 4;
+      const int n = e_cb * QBN + nblk * 32 + nq * 4;
       const bool nok = n < p.Cout;
-      const int ne = nok ? n : 0;
 #pragma unroll
       for (int mblk = 0; mblk < 2; ++mblk) {
         const f32x16 p0 = (acc[0][mblk][nblk] + acc[1][mblk][nblk]) + acc[2][mblk][nblk];
@@ -368,6 +483,14 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
           *reinterpret_cast<f32x4*>(wbase + mblk * 32 + 8 * k) = f32x4{p0[4 * k], p0[4 * k + 1], p0[4 * k + 2], p0[4 * k + 3]};
           *reinterpret_cast<f32x4*>(wbase + QEPL + mblk * 32 + 8 * k) = f32x4{p1[4 * k], p1[4 * k + 1], p1[4 * k + 2], p1[4 * k + 3]};
         }
+      }
+      if (nblk == 0) {
+        // the next tile's constants, staging items and raw chunks 0 and 1 are put in flight (half of the accumulators are dead)
+        decode_tile(vtile);
+        set_items();
+        load_raw(c_begin, rh);
+        load_raw(c1, rh2);
+        stage_consts(cst + (par ^ 1) * QCST_F);
       }
       __syncthreads();
       {
@@ -391,10 +514,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
             f32x4 v = f32x4{y[pp][0][k], y[pp][1][k], y[pp][2][k], y[pp][3][k]};
             if (direct) {
               v += base[nblk];
-              if (has_res) {
-                const float* rp = (ne < p.RC0) ? p.res0 + pix * p.RC0 + ne : p.res1 + pix * p.RC1 + (ne - p.RC0);
-                v += *reinterpret_cast<const f32x4*>(rp);
-              }
+              if (has_res) v += addv[nblk][pp][k];
               if (stats) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { const double dv = (double)v[c]; s1[nblk][c] += dv; s2[nblk][c] += dv * dv; }
@@ -430,11 +550,12 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
         const int cq = tid & 7, e = tid >> 3;             // e = which * 8 + nb2 * 4 + k
         const double a = part[16 * PR + tid] + part[16 * PR + 128 + tid];
         const int which = e >> 3, c = ((e >> 2) & 1) * 32 + cq * 4 + (e & 3);
-        const int nn = cb * QBN + c;
-        if (nn < p.Cout) p.ostat[(((size_t)b0 * T + (th_i * g.tiles_w + tw_i)) * p.Cout + nn) * 2 + which] = a;
+        const int nn = e_cb * QBN + c;
+        if (nn < p.Cout) p.ostat[(((size_t)e_b0 * T + e_tix) * p.Cout + nn) * 2 + which] = a;
       }
     }
-    __syncthreads();                                    // LDS is free for the next tile
+    par ^= 1;
+    if (!has_next) break;
   }
 }
 
@@ -448,9 +569,28 @@ int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* u
   }();
   const long ntiles = wino_workgroups(p, g);
   dim3 grid((unsigned)std::min<long>(ntiles, n_cu > 0 ? n_cu : 256), p.ksplit);
-  static std::atomic<uint64_t> done{0};
-  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino4<0>), Q_SMEM, done)) return rc;
-  hipLaunchKernelGGL((k_conv3x3_wino4<0>), grid, dim3(QNT), Q_SMEM, st, p, g, reinterpret_cast<const __bf16*>(ufrag));
+  static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
+#define SR3_W4_LAUNCH(D)                                                                                              \
+  {                                                                                                                   \
+    static std::atomic<uint64_t> done{0};                                                                             \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino4<D>), Q_SMEM, done)) return rc;          \
+    hipLaunchKernelGGL((k_conv3x3_wino4<D>), grid, dim3(QNT), Q_SMEM, st, p, g, reinterpret_cast<const __bf16*>(ufrag)); \
+  }
+  switch (dbg) {
+    case 0: SR3_W4_LAUNCH(0) break;
+#ifdef SR3_WINO_ABLATIONS
+    case 1: SR3_W4_LAUNCH(1) break;
+    case 4: SR3_W4_LAUNCH(4) break;
+    case 8: SR3_W4_LAUNCH(8) break;
+    case 16: SR3_W4_LAUNCH(16) break;
+    case 32: SR3_W4_LAUNCH(32) break;
+    case 128: SR3_W4_LAUNCH(128) break;
+    case 180: SR3_W4_LAUNCH(180) break;        // 4 + 16 + 32 + 128: the bare MFMA loop + prologue / epilogue
+    case 181: SR3_W4_LAUNCH(181) break;        // ... without the MFMAs: prologue / epilogue only
+#endif
+    default: set_error("conv: SR3_WINO_DBG=%d is not built for the four-wave kernel", dbg); return SR3_E_BADARG;
+  }
+#undef SR3_W4_LAUNCH
   SR3_LAUNCH_CHECK("k_conv3x3_wino4");
   return SR3_OK;
 }
