@@ -34,21 +34,6 @@ namespace sr3 {
 __device__ __forceinline__ float silu_h(float v) { return SR3_SILU(v); }
 
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits): each residual is exact in fp32
-__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 hh = (__bf16)v[e];
-    const float r1 = v[e] - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
-  }
-}
-
 // MODE 0: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  MODE 1 (opt-in, experimental): every fp32 operand is
 // split into three bf16 terms in the staging step and each product is evaluated as the six bf16 MFMA products
 // hh + hm + mh + mm + hl + lh (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the dropped terms are <= 2^-23 of

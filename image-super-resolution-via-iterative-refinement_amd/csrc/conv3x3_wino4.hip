@@ -62,7 +62,9 @@ __device__ __forceinline__ void split3x8q(const f32x4& lo, const f32x4& hi, qbf1
 }
 }  // namespace
 
-template <int DBG>
+// ACT: the prologue of the input (0 none, 1 GroupNorm affine, 2 affine + SiLU) as a template argument: the staging step must be
+// one basic block to be interleaved with an MFMA group
+template <int DBG, int ACT>
 __global__ __launch_bounds__(QNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restrict__ ufrag) {
   extern __shared__ f32x4 smem_q[];
@@ -124,15 +126,6 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
 #pragma unroll
     for (int j = 0; j < QHI; ++j) reinterpret_cast<qint2*>(ptab)[j * QNT + tid] = qint2{hinfo_r[j], hpix[j]};
   };
-  auto fetch_items = [&]() {
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-#pragma unroll
-    for (int j = 0; j < QHI; ++j) {
-      const qint2 v = reinterpret_cast<const qint2*>(ptab)[j * QNT + t_];
-      hinfo_r[j] = v.x; hpix[j] = v.y;
-    }
-  };
   f32x4 rh[QHI];            // staging registers of the main loop (and of a tile's chunk 0)
   f32x4 rh2[QHI];           // ... of a tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
   auto load_raw = [&](int chunk, f32x4 (&rh)[QHI]) {
@@ -152,7 +145,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool hvalid = chunk * QCK + kq * 4 < Cin;
     f32x4 ssa = zero, ssb = zero;
-    if (p.act != 0) {
+    if (ACT != 0) {
       const float* q = cs_ + 64 + (chunk - c_begin) * (2 * QCK) + kq * 8;
       ssa = *reinterpret_cast<const f32x4*>(q);
       ssb = *reinterpret_cast<const f32x4*>(q + 4);
@@ -161,12 +154,12 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     for (int j = 0; j < QHI; ++j) {
       if (hinfo_r[j] >= 0) {
         f32x4 v = rh[j];
-        if (p.act != 0) {
+        if (ACT != 0) {
           v.x = fmaf(v.x, ssa.x, ssa.y);
           v.y = fmaf(v.y, ssa.z, ssa.w);
           v.z = fmaf(v.z, ssb.x, ssb.y);
           v.w = fmaf(v.w, ssb.z, ssb.w);
-          if (p.act == 2) { v.x = silu_q(v.x); v.y = silu_q(v.y); v.z = silu_q(v.z); v.w = silu_q(v.w); }
+          if (ACT == 2) { v.x = silu_q(v.x); v.y = silu_q(v.y); v.z = silu_q(v.z); v.w = silu_q(v.w); }
         }
         v = (hvalid && hpix[j] >= 0) ? v : zero;
         *reinterpret_cast<f32x4*>(&raw[hinfo_r[j] + kq * 4]) = v;
@@ -182,7 +175,7 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool hvalid = chunk * QCK + kq * 4 < Cin;
     f32x4 ssa = zero, ssb = zero;
-    if (p.act != 0) {
+    if (ACT != 0) {
       const float* q = cs_ + 64 + (chunk - c_begin) * (2 * QCK) + kq * 8;
       ssa = *reinterpret_cast<const f32x4*>(q);
       ssb = *reinterpret_cast<const f32x4*>(q + 4);
@@ -198,12 +191,12 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
       const int j = 3 * h + jj;
       const qint2 it = reinterpret_cast<const qint2*>(ptab)[j * QNT + tid];      // (LDS offset | -1, source pixel | -1)
       f32x4 v = rh[j];
-      if (p.act != 0) {
+      if (ACT != 0) {
         v.x = fmaf(v.x, ssa.x, ssa.y);
         v.y = fmaf(v.y, ssa.z, ssa.w);
         v.z = fmaf(v.z, ssb.x, ssb.y);
         v.w = fmaf(v.w, ssb.z, ssb.w);
-        if (p.act == 2) { v.x = silu_q(v.x); v.y = silu_q(v.y); v.z = silu_q(v.z); v.w = silu_q(v.w); }
+        if (ACT == 2) { v.x = silu_q(v.x); v.y = silu_q(v.y); v.z = silu_q(v.z); v.w = silu_q(v.w); }
       }
       v = (hvalid && it.y >= 0) ? v : zero;
       float* dstp = (on && it.x >= 0) ? raw + it.x + kq * 4 : dummy_slot;
@@ -225,11 +218,11 @@ void k_conv3x3_wino4(const ConvParams p, const WinoGeom g, const __bf16* __restr
       }
       *reinterpret_cast<f32x4*>(cs_ + tid * 4) = v;
     }
-    const float* q = p.act != 0 ? p.ss + (size_t)b0 * Cin * 2 : dummy;
+    const float* q = ACT != 0 ? p.ss + (size_t)b0 * Cin * 2 : dummy;
     for (int e = tid; e < nck * (2 * QCK) / 4; e += QNT) {
       const int ch = c_begin * QCK + e * 2;
       f32x4 v = zero;
-      if (p.act != 0 && ch < Cin) v = *reinterpret_cast<const f32x4*>(q + (size_t)ch * 2);
+      if (ACT != 0 && ch < Cin) v = *reinterpret_cast<const f32x4*>(q + (size_t)ch * 2);
       *reinterpret_cast<f32x4*>(cs_ + 64 + e * 4) = v;
     }
   };
@@ -570,14 +563,17 @@ int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* u
   const long ntiles = wino_workgroups(p, g);
   dim3 grid((unsigned)std::min<long>(ntiles, n_cu > 0 ? n_cu : 256), p.ksplit);
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
-#define SR3_W4_LAUNCH(D)                                                                                              \
+#define SR3_W4_LAUNCH2(D, A)                                                                                              \
   {                                                                                                                   \
     static std::atomic<uint64_t> done{0};                                                                             \
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino4<D>), Q_SMEM, done)) return rc;          \
-    hipLaunchKernelGGL((k_conv3x3_wino4<D>), grid, dim3(QNT), Q_SMEM, st, p, g, reinterpret_cast<const __bf16*>(ufrag)); \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino4<D, A>), Q_SMEM, done)) return rc;       \
+    hipLaunchKernelGGL((k_conv3x3_wino4<D, A>), grid, dim3(QNT), Q_SMEM, st, p, g, reinterpret_cast<const __bf16*>(ufrag)); \
   }
+#define SR3_W4_LAUNCH(D) { if (p.act == 2) SR3_W4_LAUNCH2(D, 2) else if (p.act == 1) SR3_W4_LAUNCH2(0, 1) else SR3_W4_LAUNCH2(0, 0) }   /* (ablations: act = 2 layers) */
   switch (dbg) {
-    case 0: SR3_W4_LAUNCH(0) break;
+    case 0:
+      if (p.act == 2) SR3_W4_LAUNCH2(0, 2) else if (p.act == 1) SR3_W4_LAUNCH2(0, 1) else SR3_W4_LAUNCH2(0, 0)
+      break;
 #ifdef SR3_WINO_ABLATIONS
     case 1: SR3_W4_LAUNCH(1) break;
     case 4: SR3_W4_LAUNCH(4) break;
@@ -591,6 +587,7 @@ int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* u
     default: set_error("conv: SR3_WINO_DBG=%d is not built for the four-wave kernel", dbg); return SR3_E_BADARG;
   }
 #undef SR3_W4_LAUNCH
+#undef SR3_W4_LAUNCH2
   SR3_LAUNCH_CHECK("k_conv3x3_wino4");
   return SR3_OK;
 }

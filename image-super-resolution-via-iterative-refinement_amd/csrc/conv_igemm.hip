@@ -15,6 +15,15 @@
 // Block = 256 threads = 2x2 waves, tile BM x BN, k-step 32 channels of one filter tap,
 // double-buffered LDS with register staging (global -> VGPR -> [GN/SiLU] -> LDS), one barrier
 // per k-step.  Split-K writes fp32 slabs that a second kernel reduces (deterministic).
+//
+// SPLIT instantiations (ConvParams::igemm_split; plan option `gemm_split`): the same loader, prologue and epilogue on the
+// bf16 matrix pipe without losing bits -- every fp32 operand is written to LDS as three bf16 planes (x = h + m + l, 8 + 8 + 8
+// significant bits, each residual exact in fp32) while it is staged, and a product is the six v_mfma_f32_32x32x16_bf16
+// products hh + hm + mh + mm + hl + lh with fp32 accumulation (dropped terms <= 2^-24 of a product): 6/16 of the fp32
+// instruction's matrix-pipe time, and -- unlike the fp32 MFMA -- it runs beside the staging VALU work.  LDS rows are 32 bf16
+// (64 bytes, no padding), their four 16-byte segments XOR-swizzled with (row >> 2) & 3 (conv3x3_halo.hip's MODE 1 layout:
+// 8-byte staging writes and 16-byte fragment reads both conflict-free).  The 128 x 128 tile single-buffers its 48 KB stage
+// (two workgroups per CU; the second barrier of a k-step is covered by the other workgroup), the smaller tiles double-buffer.
 #include <stdlib.h>
 
 #include "sr3_common.h"
@@ -26,13 +35,15 @@ __device__ __forceinline__ float silu_f(float v) {
   return SR3_SILU(v);
 }
 
-template <int BM, int BN, int TAPS>
+template <int BM, int BN, int TAPS, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
-  constexpr int BK = 32, LDK = 36;
+  constexpr int BK = 32, LDK = 36, LDB = 32;
+  constexpr int NST = (SPLIT && BM + BN > 192) ? 1 : 2;      // LDS stages
   constexpr int AR = BM / 32, BR = BN / 32;  // loader rows per thread
   constexpr int WM = BM / 2, WN = BN / 2;    // wave tile, 2x2 waves
   constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int STAGE = SPLIT ? (BM + BN) * LDB * 3 / 2 : (BM + BN) * LDK;     // floats per stage
+  auto swz = [](int row, int seg) { return row * LDB + (((seg ^ (row >> 2)) & 3) << 3); };   // bf16 index of a 16-byte segment
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
 
@@ -144,11 +155,33 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
         }
       }
       v = aok[i] ? v : zero;     // zero padding is applied AFTER the activation, as the reference does
-      *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
+      if constexpr (SPLIT) {
+        __bf16* Ab = reinterpret_cast<__bf16*>(A);            // planes [3][BM][LDB]
+        bf16x4 h, m, l;
+        split3(v, h, m, l);
+        const int o = swz(lrow + 32 * i, kq >> 1) + (kq & 1) * 4;
+        *reinterpret_cast<bf16x4*>(&Ab[o]) = h;
+        *reinterpret_cast<bf16x4*>(&Ab[BM * LDB + o]) = m;
+        *reinterpret_cast<bf16x4*>(&Ab[2 * BM * LDB + o]) = l;
+      } else {
+        *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = wok[j] ? rw[j] : zero;
+    for (int j = 0; j < BR; ++j) {
+      const f32x4 v = wok[j] ? rw[j] : zero;
+      if constexpr (SPLIT) {
+        __bf16* Bb = reinterpret_cast<__bf16*>(A) + 3 * BM * LDB;     // planes [3][BN][LDB]
+        bf16x4 h, m, l;
+        split3(v, h, m, l);
+        const int o = swz(lrow + 32 * j, kq >> 1) + (kq & 1) * 4;
+        *reinterpret_cast<bf16x4*>(&Bb[o]) = h;
+        *reinterpret_cast<bf16x4*>(&Bb[BN * LDB + o]) = m;
+        *reinterpret_cast<bf16x4*>(&Bb[2 * BN * LDB + o]) = l;
+      } else {
+        *reinterpret_cast<f32x4*>(&Bw[(lrow + 32 * j) * LDK + kq * 4]) = v;
+      }
+    }
   };
 
   f32x16 acc[MI][NI];
@@ -167,6 +200,37 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   auto compute = [&](int stage) {
     const float* A = smem + stage * STAGE;
     const float* Bw = A + BM * LDK;
+    if constexpr (SPLIT) {
+      const __bf16* Ab = reinterpret_cast<const __bf16*>(A);
+      const __bf16* Bb = Ab + 3 * BM * LDB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {              // two K = 16 steps per 32-channel k-step
+        const int seg = ks * 2 + (lane >> 5);       // 16-byte segment (8 channels) of the row
+        bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int o = swz(arow + 32 * i, seg);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) a[i][pl] = *reinterpret_cast<const bf16x8*>(&Ab[pl * BM * LDB + o]);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int o = swz(brow + 32 * j, seg);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * BN * LDB + o]);
+        }
+        // product-major order (independent accumulators between dependent MFMAs), smallest terms first
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b[j][PB[q]], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[MI], b[NI];
@@ -189,11 +253,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     store_lds(0);
     __syncthreads();
     for (int it = it0; it < it1; ++it) {
-      const int cur = (it - it0) & 1;
+      const int cur = NST == 2 ? (it - it0) & 1 : 0;
       const bool more = it + 1 < it1;
-      if (more && !(p.dbg & 2)) load_global(it + 1);
+      if (more && !(p.dbg & 6)) load_global(it + 1);
       if (!(p.dbg & 1)) compute(cur);
-      if (more && !(p.dbg & 2)) store_lds(cur ^ 1);
+      if constexpr (NST == 1) __syncthreads();        // single stage: every wave has read its fragments
+      if (more && !(p.dbg & 10)) store_lds(NST == 2 ? cur ^ 1 : 0);
+      if (p.dbg & 8) {                                // (ablation: the loads stay, their use does not)
+#pragma unroll
+        for (int i = 0; i < AR; ++i) asm volatile("" :: "v"(ra[i]));
+#pragma unroll
+        for (int j = 0; j < BR; ++j) asm volatile("" :: "v"(rw[j]));
+      }
       __syncthreads();
     }
   }
@@ -303,11 +374,11 @@ const TileCfg kCfgs[5] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <int BM, int BN, int TAPS>
+template <int BM, int BN, int TAPS, bool SPLIT = false>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
-  constexpr int smem = 2 * (BM + BN) * 36 * 4;
-  auto kern = k_conv_igemm<BM, BN, TAPS>;
+  constexpr int smem = SPLIT ? ((BM + BN > 192) ? 1 : 2) * (BM + BN) * 192 : 2 * (BM + BN) * 36 * 4;
+  auto kern = k_conv_igemm<BM, BN, TAPS, SPLIT>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc;
   const int M = p.B * p.Ho * p.Wo;
   dim3 grid(cdiv(M, BM) * cdiv(p.Cout, BN), p.ksplit);
@@ -335,6 +406,16 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
         tile_cfg = 9;     // 8-wave 256x128 tile: half the weight traffic, when it still fills every CU
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
     }
+  }
+  if (tile_cfg == 0 && p.igemm_split && (p.ksize == 1 || p.stride == 2)) {
+    // 3 x bf16 split instantiations, from the sweep over every 1x1 / stride-2 shape of the C2 forward at batch 16
+    // (profiles/r04f_gemm_split_sweep.txt): the 128x128 tile (64x64 per wave: the only one whose fragment reads stay well
+    // under the MFMA time) where it still gives 1.5 workgroups per CU, else 64x128, else 64x64 (+ split-K below)
+    const long t14 = (long)cdiv(M, 128) * cdiv(p.Cout, 128), t17 = (long)cdiv(M, 64) * cdiv(p.Cout, 128);
+    if (p.Cout > 64 && t14 >= 384) tile_cfg = 1;
+    else if (p.Cout > 64 && (t17 >= 384 || (taps == 9 && t17 >= 128))) tile_cfg = 4;
+    else if (p.Cout <= 64 && taps == 9) tile_cfg = 2;
+    else tile_cfg = 3;
   }
   if (tile_cfg == 0 && p.ksize == 1) tile_cfg = 3;   // 1x1 convs: the 64x64 tile measured fastest on every layer shape of the
                                                      // BASELINE networks (76-81 vs 58-64 TF at 16x16, 78 vs 69 at 128x128)
@@ -468,6 +549,13 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
     const int nchunks = cdiv(Cin, 32);
     if ((long)(ksplit - 1) * cdiv(nchunks, ksplit) >= nchunks && ksplit > 1) { set_error("conv: ksplit %d leaves an empty split over %d chunks", ksplit, nchunks); return SR3_E_BADARG; }
     rc = conv3x3_halo_forward(p, tile_cfg, g, st);
+  } else
+  if (p.igemm_split) switch (tile_cfg) {
+    case 1: rc = k3 ? launch_conv<128, 128, 9, true>(p, st) : launch_conv<128, 128, 1, true>(p, st); break;
+    case 2: rc = k3 ? launch_conv<128, 64, 9, true>(p, st) : launch_conv<128, 64, 1, true>(p, st); break;
+    case 3: rc = k3 ? launch_conv<64, 64, 9, true>(p, st) : launch_conv<64, 64, 1, true>(p, st); break;
+    case 4: rc = k3 ? launch_conv<64, 128, 9, true>(p, st) : launch_conv<64, 128, 1, true>(p, st); break;
+    default: set_error("conv: bad tile_cfg %d", tile_cfg); return SR3_E_BADARG;
   } else
   switch (tile_cfg) {
     case 1: rc = k3 ? launch_conv<128, 128, 9>(p, st) : launch_conv<128, 128, 1>(p, st); break;

@@ -400,6 +400,7 @@ struct Builder {
         o.wino_off += wino_weight_floats(Cout, C0 + C1);
       }
     }
+    c.igemm_split = P->gemm_split;             // read by conv_pick / conv_forward only when the conv lands on the im2col kernel
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
       o.tile_cfg = 5; o.ksplit = P->ksplit;
@@ -936,7 +937,9 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
   out->kind = (int)o.kind * 10;
   if (o.kind == OP_CONV) {
     const ConvParams& c = o.cp;
-    out->tile_cfg = (o.tile_cfg == 11 && o.cp.wino_split) ? 11 + o.cp.wino_split : o.tile_cfg; out->ksplit = o.ksplit;
+    out->tile_cfg = (o.tile_cfg == 11 && o.cp.wino_split) ? 11 + o.cp.wino_split
+                    : (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) ? 13 + o.tile_cfg : o.tile_cfg;
+    out->ksplit = o.ksplit;
     out->ksize = c.ksize; out->stride = c.stride; out->upsample = c.ups;
     out->cin = c.C0 + c.C1; out->cout = c.Cout; out->h_out = c.Ho; out->w_out = c.Wo;
     out->fused_res_conv_cin = o.has_x2 ? c.x2_C0 + c.x2_C1 : 0;
@@ -968,6 +971,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
+  else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "wino4")) slot = &plan->wino4;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
@@ -1092,6 +1096,7 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
           static const int base[13] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305, 405, 505};
           kind += base[(o.tile_cfg == 11 && o.cp.wino_split) ? 12 : o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
           if (o.tile_cfg == 11 && o.cp.wino_split == 2) kind += 20;                         // 575: the four-wave split kernel
+          if (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) kind += 600;           // 651-654: the im2col tiles on their 3 x bf16 split instantiation
           WinoGeom wg;
           if (o.tile_cfg == 11 && wino_geometry(o.cp, &wg) && wg.NB != 1) kind += 10;      // 465: the four-image 8x8 tile
         }
@@ -1157,6 +1162,7 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
   const bool wsplit = tile_cfg == 12 || tile_cfg == 13;     // tile 11 on the 3 x bf16 split instantiation (13: its four-wave form)
   if (wsplit) { c.wino_split = tile_cfg - 11; tile_cfg = 11; }
+  if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }     // the im2col tiles 1-4 on their 3 x bf16 split instantiation
   if (tile_cfg == 11 && (ksize != 3 || stride != 1)) { set_error("conv: the Winograd kernel does not fit this problem (3x3 stride 1 only)"); return SR3_E_UNSUPPORTED; }
   if (tile_cfg == 11) {
     // Winograd form through the per-op entry: the transformed filters are derived here, behind the split-K slabs in
@@ -1242,6 +1248,7 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
     c.Hs = Ho; c.Ws = Wo; c.stride = 1;
     return conv_splitk_bytes(c, 11, ksplit) + wino_weight_floats(Cout, Cin, tile_cfg >= 12) * sizeof(float);
   }
+  if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
   // the entry does not know the stride: take the larger of the stride-1 (halo kernel eligible) and the im2col sizing
   const size_t a = conv_splitk_bytes(c, tile_cfg, ksplit);
   c.Hs = Ho; c.Ws = Wo; c.stride = 1;
@@ -1259,6 +1266,7 @@ int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int
   c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = 1; c.ksize = 3; c.Ho = Hs << ups; c.Wo = Ws << ups;
   c.Cout = Cout; c.C0 = Cin;
   if (tile_cfg == 12 || tile_cfg == 13) tile_cfg = 11;
+  if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
   conv_pick(c, tile_cfg, ksplit);
   if (ksplit > 1) {
     const int rpb = splitk_rows_per_block(c, true);

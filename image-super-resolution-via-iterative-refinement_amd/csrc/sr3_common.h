@@ -13,6 +13,21 @@ namespace sr3 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits): each residual is exact in fp32
+__device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)v[e];
+    const float r1 = v[e] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+  }
+}
+
 // sigmoid / SiLU of the staging and activation-backward steps: libm expf (1 ulp) and the hardware reciprocal v_rcp_f32
 // (1 ulp).  Measured against float64 autograd at batch 64 (profiles/r04_grad_probe.txt): parameter gradients are within 5e-7
 // of float64 with these, the same as with an IEEE division (-DSR3_EXACT_ACT, A/B builds only) and as stock PyTorch-ROCm.
@@ -93,7 +108,7 @@ struct ConvParams {
   float* partial;      // split-K scratch [ksplit][M][Cout] (ksplit > 1)
   int ksplit;
   double* ostat;       // optional (halo kernel only): partial {sum, sumsq} of the OUTPUT, [B][T][Cout][2]
-  int dbg;             // profiling ablations only (env SR3_CONV_DBG): 1 = skip MFMA, 2 = skip staging
+  int dbg;             // profiling ablations only (env SR3_CONV_DBG): 1 = skip MFMA + fragment reads, 2 = skip staging, 4 = skip the global loads only, 8 = skip the LDS writes (and the split) only
   // Optional second K-segment (halo kernel only): a 1x1 conv of another tensor (virtual concat
   // x2_src0|x2_src1, same spatial size as the output, no prologue) accumulated into the same
   // output tile -- ResnetBlock's `res_conv(x)` (unet.py:102-103,110) folded into block2's conv.
@@ -112,6 +127,7 @@ struct ConvParams {
   const float* wino_u;
   int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI);
                        // 2: the same filters on the four-wave kernel of conv3x3_wino4.hip (tile_cfg 13)
+  int igemm_split;     // im2col kernel (tile_cfg 1-4; 1x1 and stride-2 convs): 1 = its 3 x bf16 split instantiation (tile_cfg 14-17 at the ABI)
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -122,7 +138,8 @@ __device__ __forceinline__ float drop_mask(unsigned seed, unsigned idx, unsigned
   return hash32(idx * 0x9E3779B9U + seed) >= thresh ? scale : 0.f;
 }
 
-// tile_cfg: 0 = auto; im2col-staged implicit GEMM: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128;
+// tile_cfg: 0 = auto; im2col-staged implicit GEMM: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 (ConvParams::igemm_split
+// selects the 3 x bf16 split instantiation of the same tiles);
 // halo-tile 3x3 stride-1 kernel: 5 = 128x128, 6 = 256(M)x64(N).  ksplit: 0 = auto
 int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_scratch,
                  size_t splitk_scratch_bytes, hipStream_t st);

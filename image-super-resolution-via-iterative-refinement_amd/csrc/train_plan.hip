@@ -54,6 +54,7 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
     c.wino_u = wu;
     return conv_forward(c, 11, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
   }
+  c.igemm_split = X.P->gemm_split;             // 1x1 / 8x8 data gradients on the im2col kernel: its 3 x bf16 split instantiation, as the forward
   return conv_forward(c, 0, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
 }
 

@@ -91,7 +91,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "loss_l2"};
+ * "wino_split", "gemm_split", "wino4", "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
  *   split instantiation: every fp32 operand as x = h + m + l (three bf16 terms, each residual exact in fp32), every product as
@@ -99,6 +99,10 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   (dropped terms <= 2^-24 of a product; measured not less accurate than the fp32-MFMA instantiation on every layer shape,
  *   tests/test_gpu_ops.py), not the bit pattern of the fp32 MFMA.  The derived buffer then holds both forms of every filter
  *   (sr3_plan_derived_bytes grows 2.5x; re-bind after toggling).  0: v_mfma_f32_32x32x2_f32 everywhere.
+ * gemm_split (default 1): the same 3 x bf16 split arithmetic for the convolutions of the im2col kernel (every 1x1 conv --
+ *   res_conv, attention qkv / out -- and the stride-2 Downsample convs), operands split while they are staged into LDS.
+ *   0: v_mfma_f32_32x32x2_f32.
+ * wino4 (default 0, experimental): wino_split convolutions on the four-wave, 512-register kernel (conv3x3_wino4.hip).
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
  * split_bf16 (default 0, experimental): run the halo-tile 3x3 convolutions of the inference plan on
@@ -227,7 +231,9 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * weights OHWI.  tile_cfg/ksplit 0 = auto (direct kernels only); tile_cfg 11 = Winograd F(2x2,3x3) (3x3 stride 1, H and W
  * multiples of 16, or 8x8 maps with B % 4 == 0 -- four images per workgroup tile, split-K only; the transformed filters are
  * derived into `scratch` by this entry point); tile_cfg 12 = the same kernel's 3 x bf16 split instantiation (one-image tile
- * only; what plan option wino_split selects).
+ * only; what plan option wino_split selects), 13 = its four-wave experimental form (plan option wino4); tile_cfg 1-4 = the
+ * im2col kernel's 128x128 / 128x64 / 64x64 / 64x128 tiles on the exact-fp32 MFMA, 14-17 = the same tiles on the 3 x bf16 split
+ * instantiation (what plan option gemm_split selects).
  * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11), sized by sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
                  int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,

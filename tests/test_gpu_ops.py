@@ -143,7 +143,8 @@ def _make_case(case, seed=1):
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
 @pytest.mark.parametrize('tile_cfg,ksplit', [(0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (1, 3), (3, 2), (5, 1), (6, 1), (5, 2),
                                              (6, 2), (7, 1), (8, 1), (7, 2), (9, 1), (10, 1), (9, 2), (10, 3),
-                                             (11, 1), (11, 2), (11, 0)])
+                                             (11, 1), (11, 2), (11, 0),
+                                             (14, 1), (15, 1), (16, 1), (17, 1), (14, 3), (16, 2)])
 def test_conv(case, tile_cfg, ksplit):
     src0, src1, w, kw = _make_case(case)
     total = ((src0.shape[1] + (0 if src1 is None else src1.shape[1]) + 31) // 32) * w.shape[2] * w.shape[3]
@@ -312,6 +313,46 @@ def test_winograd_split_error_not_above_fp32_winograd(case, ksplit, tile):
           % (case[0], ksplit, tile, e_s, rms_s, e_w, rms_w, ref.abs().max().item()))
     assert rms_s <= 1.05 * rms_w, (rms_s, rms_w)
     assert e_s <= 1.25 * e_w + 1e-8 * ref.abs().max().item(), (e_s, e_w)
+
+
+# every kind of 1x1 / stride-2 conv of the BASELINE networks (name, B, C0, C1, H, W, Cout, k, stride, ups, act, film, res, bias)
+GEMM_SPLIT_CASES = [
+    ('qkv_16', 2, 512, 0, 16, 16, 1536, 1, 1, 0, 1, False, False, False),
+    ('attn_out_16', 2, 512, 0, 16, 16, 512, 1, 1, 0, 0, False, True, True),
+    ('res_conv_1024_16', 2, 512, 512, 16, 16, 512, 1, 1, 0, 0, False, False, True),
+    ('res_conv_192_128', 1, 128, 64, 128, 128, 64, 1, 1, 0, 0, False, False, True),
+    ('res_conv_64_64', 2, 64, 0, 64, 64, 128, 1, 1, 0, 0, False, False, True),
+    ('qkv_64x64_c1024', 1, 1024, 0, 32, 32, 3072, 1, 1, 0, 1, False, False, False),
+    ('down_128', 1, 64, 0, 128, 128, 64, 3, 2, 0, 0, False, False, True),
+    ('down_16', 2, 512, 0, 16, 16, 512, 3, 2, 0, 0, False, False, True),
+]
+
+
+@pytest.mark.parametrize('tile,ksplit', [(14, 1), (15, 1), (16, 1), (17, 1), (15, 2), (0, 0)])
+@pytest.mark.parametrize('case', GEMM_SPLIT_CASES, ids=[c[0] for c in GEMM_SPLIT_CASES])
+def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
+    """Gate of the `gemm_split` plan option (tiles 14-17: the im2col kernel's 3 x bf16 split instantiations -- operands split
+    into h + m + l while they are staged, six bf16 MFMA products per term, fp32 accumulation): on the 1x1 / stride-2 layer
+    shapes of the BASELINE networks the error against float64 is not above the exact-fp32 instantiation's (tile 3) on the
+    same data, and the stated tolerance holds.  (0, 0) is the ABI's auto pick, which stays on the fp32 MFMA."""
+    if tile in (14, 17) and case[6] <= 64:
+        pytest.skip('128-wide tiles are not used for Cout <= 64')
+    src0, src1, w, kw = _make_case(case, seed=11)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
+    base, _ = G.conv_call(src0, src1, w, tile_cfg=3, ksplit=ksplit, **kw)
+    assert not torch.isnan(got).any()
+    e_s = G.assert_close(got, ref, what=case[0] + ' (im2col, 3 x bf16 split)')
+    e_f = G.assert_close(base, ref, what=case[0] + ' (im2col, fp32 MFMA)')
+    rms_s = (got.double() - ref).pow(2).mean().sqrt().item()
+    rms_f = (base.double() - ref).pow(2).mean().sqrt().item()
+    scale = ref.abs().max().item()
+    print('%s tile %d ks%d: max/rms err split %.2e/%.2e  fp32 MFMA %.2e/%.2e  |ref|max %.2f' % (case[0], tile, ksplit, e_s, rms_s, e_f, rms_f, scale))
+    if tile == 0:
+        assert torch.equal(got, base) or e_s <= 2.0 * e_f
+        return
+    assert rms_s <= 1.1 * rms_f + 1e-9 * scale, (rms_s, rms_f)
+    assert e_s <= 1.5 * e_f + 1e-8 * scale, (e_s, e_f)
 
 
 @pytest.mark.parametrize('K', [(64, 0), (512, 0), (512, 512)], ids=['K576', 'K4608', 'K9216'])

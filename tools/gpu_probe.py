@@ -85,16 +85,16 @@ def conv_sweep(B, out_path, quick=False, only=None, cfgs=(1, 2, 3, 4), kss=(1, 2
             flops = 2.0 * B * Ho * Ho * Cout * Cin * k * k
             total_it = ((Cin + 31) // 32) * k * k
             for cfg in cfgs:
-                if cfg in (1, 4) and Cout <= 64:
+                if cfg in (1, 4, 14, 17) and Cout <= 64:
                     continue
-                if cfg >= 5 and (k != 3 or stride != 1):
+                if 5 <= cfg <= 13 and (k != 3 or stride != 1):
                     continue
                 for ks in kss:
                     if ks > 1 and (ks * 4 > total_it):
                         continue
-                    if cfg >= 5 and ks > 1 and ks * 2 > (Cin + 31) // 32:
+                    if 5 <= cfg <= 13 and ks > 1 and ks * 2 > (Cin + 31) // 32:
                         continue
-                    bm, bn = {0: (128, 128), 1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 128), 6: (256, 64), 7: (128, 128), 8: (256, 64), 9: (256, 128), 10: (256, 128), 11: (256, 64), 12: (128, 128)}[cfg]
+                    bm, bn = {0: (128, 128), 1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (64, 128), 5: (128, 128), 6: (256, 64), 7: (128, 128), 8: (256, 64), 9: (256, 128), 10: (256, 128), 11: (256, 64), 12: (128, 128), 14: (128, 128), 15: (128, 64), 16: (64, 64), 17: (64, 128)}[cfg]
                     tiles = -(-B * Ho * Ho // bm) * -(-Cout // bn)
                     if ks > 1 and tiles * ks > 4096:
                         continue
