@@ -433,7 +433,9 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, re
     x = torch.randn(shape, device=dev, generator=g)
     tm = torch.full((B, 1), 0.6, device=dev) if un.variant == 'sr3' else torch.full((B,), 900, dtype=torch.long, device=dev)
     eps_exact = un(x, tm, cond=cond).clone()         # (the plan the headline ran on)
-    un.plan.set_option(option, value)
+    options = list(option) if isinstance(option, (list, tuple)) else [option]
+    for o in options:
+        un.plan.set_option(o, value)
     roof = None
     try:
         eps_split = un(x, tm, cond=cond).clone()
@@ -455,14 +457,15 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, re
         if with_roofline:
             roof = roofline_from_profile(netG, st2['img'], st2['cond'])
     finally:
-        un.plan.set_option(option, restore)
+        for o in options:
+            un.plan.set_option(o, restore)
         netG._loop_cache = {}
     fl = un.plan.forward_flops(B)
     return dict(ms_per_step=ms, images_per_s_per_gpu=B / (T * ms * 1e-3), step_tflops_equiv=fl / (ms * 1e-3) / 1e12,
                 steps=steps, output_finite=finite,
                 eps_max_abs_diff_vs_headline_plan=float((eps_split - eps_exact).abs().max().item()),
                 eps_max_abs=float(eps_exact.abs().max().item()), roofline=roof,
-                note='plan option %s=%d; not used for `value`' % (option, value))
+                note='plan option %s=%d; not used for `value`' % (' / '.join(options), value))
 
 
 def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
@@ -509,7 +512,7 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
 
 
-def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=False):
+def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=False, plan_opts=None):
     """define_G of a BASELINE.json network (random init, seed 0), its reverse-step hipGraph captured at batch B."""
     import torch
     import model.networks as networks
@@ -525,6 +528,9 @@ def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=F
         netG.denoise_fn.plan.set_option('split_bf16', 1)
     if exact_fp32:
         netG.denoise_fn.plan.set_option('wino_split', 0)
+        netG.denoise_fn.plan.set_option('gemm_split', 0)
+    for k, v in (plan_opts or {}).items():               # A/B runs only (--plan-opt); the record carries them in `config`
+        netG.denoise_fn.plan.set_option(k, v)
     S = cfg['size']
     torch.manual_seed(1000 + rank)                       # per-rank RNG stream / inputs
     shape = (B, 3, S, S)
@@ -643,9 +649,11 @@ def main():
                     help='skip the bounded legs of the other BASELINE.json configurations (SR3 64->512 batch 4, DDPM-128 batch 32)')
     ap.add_argument('--no-split-leg', action='store_true', help='(default now) skip the secondary split_bf16 measurement')
     ap.add_argument('--no-exact-leg', action='store_true',
-                    help='skip the secondary measurement with plan option wino_split = 0 (every Winograd conv on the fp32 MFMA)')
+                    help='skip the secondary measurement with plan options wino_split = gemm_split = 0 (every conv on the fp32 MFMA)')
     ap.add_argument('--exact-fp32', action='store_true',
-                    help='run the HEADLINE leg with wino_split = 0 (dtype is then reported as f32)')
+                    help='run the HEADLINE leg with wino_split = gemm_split = 0 (dtype is then reported as f32)')
+    ap.add_argument('--plan-opt', action='append', default=[], metavar='KEY=VALUE',
+                    help='A/B runs: set a plan option (sr3_plan_set_option) on the headline leg, e.g. --plan-opt gemm_split=0')
     ap.add_argument('--split-leg', action='store_true',
                     help='also time the opt-in split_bf16 plan option (direct halo kernels on bf16 MFMA; superseded by the fp32 '
                          'Winograd path, which is faster and exact-fp32 arithmetic)')
@@ -699,7 +707,8 @@ def main():
     T = 2000
     B = a.batch or cfg['batch']
     S = cfg['size']
-    netG, st = build_sampler(a.config, B, dev, rank, a.split_bf16, T, a.exact_fp32)
+    plan_opts = dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in a.plan_opt)
+    netG, st = build_sampler(a.config, B, dev, rank, a.split_bf16, T, a.exact_fp32, plan_opts)
     elapsed = time_replays(st, a.steps, a.warmup, T, dist, dev)
     finite = bool(torch.isfinite(st['img']).all().item())
     ms_per_step = elapsed / a.steps * 1e3
@@ -721,7 +730,8 @@ def main():
                                % (cfg['title'], cfg['ref_json'], cfg['baseline_cfg'], B),
                    'name': a.config, 'batch_per_gpu': B, 'global_batch': B * world, 'n_timestep': T, 'image_size': S,
                    'params': nparams, 'parallelism': 'independent batches per rank (no collective)',
-                   'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite},
+                   'weights': 'random init (PyTorch default, seed 0)', 'output_finite': finite,
+                   **({'plan_options_ab_run': plan_opts} if plan_opts else {})},
         'step_direct_equiv_tflops': flops_step / (ms_per_step * 1e-3) / 1e12,     # SURVEY 8d FLOPs / time (Winograd executes fewer)
         'parity_max_abs': None,
     }
@@ -755,8 +765,8 @@ def main():
         except Exception as e:
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and not a.no_exact_leg and not a.split_bf16 and not a.exact_fp32:
-        try:       # the same step with every Winograd conv on the exact-fp32 MFMA instantiation (plan option wino_split = 0)
-            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option='wino_split', value=0, restore=1,
+        try:       # the same step with every conv on the exact-fp32 MFMA instantiations (plan options wino_split = gemm_split = 0)
+            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option=('wino_split', 'gemm_split'), value=0, restore=1,
                                                with_roofline=not a.no_roofline)
             rec['exact_fp32']['dtype'] = 'f32 (v_mfma_f32_32x32x2_f32 everywhere)'
         except Exception as e:                     # the secondary leg must never cost the headline line

@@ -26,6 +26,8 @@
 // (two workgroups per CU; the second barrier of a k-step is covered by the other workgroup), the smaller tiles double-buffer.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sr3_common.h"
 
 namespace sr3 {
@@ -81,17 +83,23 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     }
   }
 
-  f32x4 ra[AR], rw[BR], ssa[AR], ssb[AR];
-  bool aok[AR], wok[BR];
-  int aoff[AR];             // element offset of the staged quad (dropout mask index)
-  int ss_chunk = -1;
+  // Two register sets: the global loads run TWO k-steps ahead of the MFMAs (set = k-step parity), so a load has a whole
+  // compute + stage phase to land even when the operands are cold (weights straight from HBM inside a forward; the split
+  // instantiations' k-steps are ~1/3 as long as the fp32 ones: with one step of prefetch they were 14-40 % slower inside the
+  // forward than in isolation, profiles/r04f_gemm_split_sweep.txt)
+  f32x4 ra[2][AR], rw[2][BR], ssa[AR], ssb[AR];       // (the GroupNorm pairs, L2-hot, stay one step ahead: one set)
+  bool aok[2][AR], wok[2][BR];
+  int aoff[2][AR];          // element offset of the staged quad (dropout mask index)
+  using SET0 = std::integral_constant<int, 0>;
+  using SET1 = std::integral_constant<int, 1>;
 
   // Every global load below is UNCONDITIONAL (out-of-range lanes read element 0 of the same
   // buffer) and the zero mask is applied when the registers are written to LDS, after the MFMA
   // block: a predicated load would put each load in its own exec-masked branch and drain vmcnt
   // at the join, exposing the full memory latency every k-step.  32-bit element offsets (host
   // checks every tensor has < 2^31 elements).
-  auto load_global = [&](int it) {
+  auto load_global = [&](auto set_tag, int it) {
+    constexpr int S = decltype(set_tag)::value;
     const int chunk = it / TAPS;
     const int tap = it - chunk * TAPS;
     const int fr = (TAPS == 9) ? tap / 3 : 0;
@@ -107,39 +115,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     for (int i = 0; i < AR; ++i) {
       const int ih = rih[i] + fr, iw = riw[i] + fs;
       const bool ok = cvalid && rb[i] >= 0 && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
-      aok[i] = ok;
+      aok[S][i] = ok;
       const int pix = (rb[i] * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
       const int off = ok ? pix * sC + cs : 0;
-      aoff[i] = off;
-      ra[i] = *reinterpret_cast<const f32x4*>(sp + off);
+      aoff[S][i] = off;
+      ra[S][i] = *reinterpret_cast<const f32x4*>(sp + off);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
       const int n = tile_n * BN + lrow + 32 * j;
       const bool ok = cvalid && n < p.Cout;
-      wok[j] = ok;
+      wok[S][j] = ok;
       const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
-      rw[j] = *reinterpret_cast<const f32x4*>(p.w + off);
+      rw[S][j] = *reinterpret_cast<const f32x4*>(p.w + off);
     }
-    if (p.act != 0 && chunk != ss_chunk) {
-      ss_chunk = chunk;
+  };
+  auto load_ss = [&](int it) {       // scale / shift pairs of the k-step that is staged next
+    const int c = (it / TAPS) * BK + kq * 4;
+    const int ce = c < Cin ? c : 0;
 #pragma unroll
-      for (int i = 0; i < AR; ++i) {
-        const int be = rb[i] >= 0 ? rb[i] : 0;
-        const float* q = p.ss + (be * Cin + ce) * 2;
-        ssa[i] = *reinterpret_cast<const f32x4*>(q);
-        ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
-      }
+    for (int i = 0; i < AR; ++i) {
+      const int be = rb[i] >= 0 ? rb[i] : 0;
+      const float* q = p.ss + (be * Cin + ce) * 2;
+      ssa[i] = *reinterpret_cast<const f32x4*>(q);
+      ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
     }
   };
 
-  auto store_lds = [&](int stage) {
+  auto store_lds = [&](auto set_tag, int stage) {
+    constexpr int S = decltype(set_tag)::value;
     float* A = smem + stage * STAGE;
     float* Bw = A + BM * LDK;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      f32x4 v = ra[i];
+      f32x4 v = ra[S][i];
       if (p.act != 0) {
         v.x = fmaf(v.x, ssa[i].x, ssa[i].y);
         v.y = fmaf(v.y, ssa[i].z, ssa[i].w);
@@ -147,14 +157,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
         v.w = fmaf(v.w, ssb[i].z, ssb[i].w);
         if (p.act == 2) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         if (p.drop_thresh != 0) {
-          const unsigned i0 = (unsigned)aoff[i];
+          const unsigned i0 = (unsigned)aoff[S][i];
           v.x *= drop_mask(p.drop_seed, i0, p.drop_thresh, p.drop_scale);
           v.y *= drop_mask(p.drop_seed, i0 + 1, p.drop_thresh, p.drop_scale);
           v.z *= drop_mask(p.drop_seed, i0 + 2, p.drop_thresh, p.drop_scale);
           v.w *= drop_mask(p.drop_seed, i0 + 3, p.drop_thresh, p.drop_scale);
         }
       }
-      v = aok[i] ? v : zero;     // zero padding is applied AFTER the activation, as the reference does
+      v = aok[S][i] ? v : zero;     // zero padding is applied AFTER the activation, as the reference does
       if constexpr (SPLIT) {
         __bf16* Ab = reinterpret_cast<__bf16*>(A);            // planes [3][BM][LDB]
         bf16x4 h, m, l;
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const f32x4 v = wok[j] ? rw[j] : zero;
+      const f32x4 v = wok[S][j] ? rw[S][j] : zero;
       if constexpr (SPLIT) {
         __bf16* Bb = reinterpret_cast<__bf16*>(A) + 3 * BM * LDB;     // planes [3][BN][LDB]
         bf16x4 h, m, l;
@@ -248,24 +258,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     }
   };
 
-  if (it0 < it1) {
-    load_global(it0);
-    store_lds(0);
+  // main loop, unrolled by two so the register set of a k-step is a compile-time constant: at the top of step i the LDS holds
+  // step i, set (i + 1) & 1 holds step i + 1 (loaded one step ago) and set i & 1 is free for step i + 2
+  const int nsteps = it1 - it0;
+  auto step = [&](auto set_cur, auto set_next, int i, int cur) {
+    if (i + 2 < nsteps && !(p.dbg & 6)) load_global(set_cur, it0 + i + 2);
+    if (i + 1 < nsteps && p.act != 0) load_ss(it0 + i + 1);
+    if (!(p.dbg & 1)) compute(cur);
+    if constexpr (NST == 1) __syncthreads();          // single stage: every wave has read its fragments
+    if (i + 1 < nsteps && !(p.dbg & 10)) store_lds(set_next, NST == 2 ? cur ^ 1 : 0);
     __syncthreads();
-    for (int it = it0; it < it1; ++it) {
-      const int cur = NST == 2 ? (it - it0) & 1 : 0;
-      const bool more = it + 1 < it1;
-      if (more && !(p.dbg & 6)) load_global(it + 1);
-      if (!(p.dbg & 1)) compute(cur);
-      if constexpr (NST == 1) __syncthreads();        // single stage: every wave has read its fragments
-      if (more && !(p.dbg & 10)) store_lds(NST == 2 ? cur ^ 1 : 0);
-      if (p.dbg & 8) {                                // (ablation: the loads stay, their use does not)
-#pragma unroll
-        for (int i = 0; i < AR; ++i) asm volatile("" :: "v"(ra[i]));
-#pragma unroll
-        for (int j = 0; j < BR; ++j) asm volatile("" :: "v"(rw[j]));
-      }
-      __syncthreads();
+  };
+  if (nsteps > 0) {
+    load_global(SET0{}, it0);
+    if (nsteps > 1) load_global(SET1{}, it0 + 1);
+    if (p.act != 0) load_ss(it0);
+    store_lds(SET0{}, 0);
+    __syncthreads();
+    for (int i = 0; i < nsteps; i += 2) {
+      step(SET0{}, SET1{}, i, 0);
+      if (i + 1 < nsteps) step(SET1{}, SET0{}, i + 1, NST == 2 ? 1 : 0);
     }
   }
 
@@ -407,16 +419,12 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       else if (halo_geometry(p, 5, &g)) tile_cfg = 5;
     }
   }
-  if (tile_cfg == 0 && p.igemm_split && (p.ksize == 1 || p.stride == 2)) {
-    // 3 x bf16 split instantiations, from the sweep over every 1x1 / stride-2 shape of the C2 forward at batch 16
-    // (profiles/r04f_gemm_split_sweep.txt): the 128x128 tile (64x64 per wave: the only one whose fragment reads stay well
-    // under the MFMA time) where it still gives 1.5 workgroups per CU, else 64x128, else 64x64 (+ split-K below)
-    const long t14 = (long)cdiv(M, 128) * cdiv(p.Cout, 128), t17 = (long)cdiv(M, 64) * cdiv(p.Cout, 128);
-    if (p.Cout > 64 && t14 >= 384) tile_cfg = 1;
-    else if (p.Cout > 64 && (t17 >= 384 || (taps == 9 && t17 >= 128))) tile_cfg = 4;
-    else if (p.Cout <= 64 && taps == 9) tile_cfg = 2;
-    else tile_cfg = 3;
-  }
+  // 3 x bf16 split instantiations: the 64x64 tile as well.  In isolation (warm operands) the larger split tiles win on most
+  // layer shapes (128x128: qkv 71 vs 94 us), but INSIDE the forward -- activations just written by the previous kernel, weights
+  // from HBM -- they lose by up to 2.5x on the short-K layers (one round of 384-512 workgroups loads, computes and stores in
+  // lock step), and per-launch timing of the whole forward with every tile forced in turn (plan option gemm_tile,
+  // profiles/r04f_gemm_split_sweep.txt) gives 64x64 2.31 / 1.96 / 1.59 / 2.02 ms for tiles 1-4 (fp32 MFMA: 2.59 / 2.27 / 1.86 / 2.34)
+  if (tile_cfg == 0 && p.igemm_split && (p.ksize == 1 || p.stride == 2)) tile_cfg = 3;
   if (tile_cfg == 0 && p.ksize == 1) tile_cfg = 3;   // 1x1 convs: the 64x64 tile measured fastest on every layer shape of the
                                                      // BASELINE networks (76-81 vs 58-64 TF at 16x16, 78 vs 69 at 128x128)
   if (tile_cfg == 0) {

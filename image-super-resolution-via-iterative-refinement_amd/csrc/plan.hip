@@ -400,8 +400,14 @@ struct Builder {
         o.wino_off += wino_weight_floats(Cout, C0 + C1);
       }
     }
-    c.igemm_split = P->gemm_split;             // read by conv_pick / conv_forward only when the conv lands on the im2col kernel
+    // read by conv_pick / conv_forward only when the conv lands on the im2col kernel; the 9-tap layers with Cout <= 64 (Downsample
+    // of the first level) stay on the fp32 MFMA, which is faster there (67 vs 81 us in the forward)
+    c.igemm_split = (P->gemm_split && !(ksize == 3 && Cout <= 64)) ? 1 : 0;
     conv_pick(c, o.tile_cfg, o.ksplit);
+    if (P->gemm_tile >= 1 && P->gemm_tile <= 4 && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->tile_cfg == 0) {
+      o.tile_cfg = P->gemm_tile; o.ksplit = P->ksplit;       // A/B knob: one im2col tile for every conv of that kernel
+      conv_pick(c, o.tile_cfg, o.ksplit);
+    }
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
       o.tile_cfg = 5; o.ksplit = P->ksplit;
       conv_pick(c, o.tile_cfg, o.ksplit);
@@ -972,6 +978,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
+  else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino4")) slot = &plan->wino4;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }

@@ -107,6 +107,7 @@ struct sr3_plan {
   int wino_split = 1;        // ... on its 3 x bf16 split instantiation (bf16 MFMA, fp32-class results; gated by tests/: error not
                              // above the fp32-MFMA instantiation's on every layer shape, 2000-step drift) where that exists: the
                              // one-image tile of the inference plan.  0: the exact-fp32 MFMA instantiation everywhere
+  int gemm_tile = 0;         // A/B knob: force this im2col tile (1-4) on every conv of that kernel; 0 = conv_pick's choice
   int gemm_split = 1;        // the im2col kernel (1x1 and stride-2 convs) on its 3 x bf16 split instantiations (conv_igemm.hip)
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };

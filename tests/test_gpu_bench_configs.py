@@ -113,8 +113,8 @@ def test_c2_batch16_forward_and_graph_step():
 
 
 def test_c2_batch16_wino_split_gate_and_exact_fp32_plan():
-    """Gate of the `wino_split` plan option (default on) at the headline configuration: the Winograd convs of maps >= 16x16
-    on the kernel's 3 x bf16 split instantiation (tile 12).  Same stated tolerance as the exact-fp32 plan (`wino_split = 0`,
+    """Gate of the `wino_split` / `gemm_split` plan options (default on) at the headline configuration: the Winograd convs of
+    maps >= 16x16 on the kernel's 3 x bf16 split instantiation (tile 12), the 1x1 / stride-2 convs on the im2col kernel's (14-17).  Same stated tolerance as the exact-fp32 plan (`wino_split = 0`,
     every Winograd conv on v_mfma_f32_32x32x2_f32) for the forward and for one replay of the production graph -- both plans
     are run -- and the forward's error against the CPU oracle must not exceed 1.5x the exact-fp32 plan's on the same input."""
     from oracle import sr3_oracle as O
@@ -127,13 +127,16 @@ def test_c2_batch16_wino_split_gate_and_exact_fp32_plan():
     with torch.no_grad():
         ref = O.unet_forward(sd, desc, x, lvl)
     netG.denoise_fn.plan.set_option('wino_split', 0)
+    netG.denoise_fn.plan.set_option('gemm_split', 0)
     cfgs = _cfgs(netG, B)
-    assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(t == 12 for t, _ in cfgs), sorted(set(cfgs))
+    assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(t == 12 or t >= 14 for t, _ in cfgs), sorted(set(cfgs))
     e_fp32 = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (fp32 Winograd)')
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2 exact fp32 (wino_split = 0)')
     netG.denoise_fn.plan.set_option('wino_split', 1)
+    netG.denoise_fn.plan.set_option('gemm_split', 1)
     cfgs = _cfgs(netG, B)
     assert (12, 1) in cfgs and (12, 2) in cfgs and (11, 8) in cfgs and not any(t == 11 and k < 8 for t, k in cfgs), sorted(set(cfgs))
+    assert (16, 1) in cfgs and (16, 4) in cfgs and not any(t in (1, 3, 4) for t, _ in cfgs), sorted(set(cfgs))   # gemm_split
     e_split = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (wino_split)')
     print('C2 batch 16: eps max abs err vs the CPU oracle: fp32 Winograd plan %.2e, wino_split plan %.2e (|ref|max %.2f)'
           % (e_fp32, e_split, ref.abs().max().item()))

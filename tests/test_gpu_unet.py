@@ -73,23 +73,27 @@ def test_unet_forward_split_bf16_option(name):
 
 @pytest.mark.parametrize('name', NAMES)
 def test_unet_forward_exact_fp32_option(name):
-    """Plan option `wino_split` (default 1: the Winograd kernel's 3 x bf16 split instantiation) switched off -- every Winograd
-    conv on the fp32 MFMA -- on the reference-generated vectors: same stated tolerance; toggling it back restores the default
-    plan's result bit for bit."""
+    """Plan options `wino_split` / `gemm_split` (default 1: the Winograd and im2col kernels' 3 x bf16 split instantiations)
+    switched off -- every conv on the fp32 MFMA -- on the reference-generated vectors: same stated tolerance; toggling them
+    back restores the default plan's result bit for bit."""
     m, g, sd = build(name)
     un = m.netG.denoise_fn
     d = G.dev()
     x, t = torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d)
-    assert un.plan.options.get('wino_split', 1) == 1
-    has12 = any(o['tile_cfg'] == 12 for o in un.plan.op_list(x.shape[0]))
+    assert un.plan.options.get('wino_split', 1) == 1 and un.plan.options.get('gemm_split', 1) == 1
+    split_tiles = (12, 14, 15, 16, 17)
+    has_split = any(o['tile_cfg'] in split_tiles for o in un.plan.op_list(x.shape[0]))
+    assert has_split, 'the default plan of %s has no conv on a split instantiation' % name
     e0 = un(x, t).clone()
     G.assert_close(e0.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (default plan)')
     un.plan.set_option('wino_split', 0)
-    assert not any(o['tile_cfg'] == 12 for o in un.plan.op_list(x.shape[0]))
+    un.plan.set_option('gemm_split', 0)
+    assert not any(o['tile_cfg'] in split_tiles for o in un.plan.op_list(x.shape[0]))
     e1 = un(x, t).clone()
-    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (wino_split = 0)')
-    assert has12 or torch.equal(e0, e1)
+    G.assert_close(e1.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps (wino_split = gemm_split = 0)')
+    print('%s: eps max abs diff default plan vs all-fp32-MFMA plan %.2e' % (name, float((e0 - e1).abs().max())))
     un.plan.set_option('wino_split', 1)
+    un.plan.set_option('gemm_split', 1)
     assert torch.equal(un(x, t), e0)
 
 
