@@ -51,13 +51,10 @@ __device__ __forceinline__ float silu_q(float v) {
 }
 __device__ __forceinline__ void split3x8q(const f32x4& lo, const f32x4& hi, qbf16x8& h, qbf16x8& m, qbf16x8& l) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float v = e < 4 ? lo[e] : hi[e - 4];
-    const __bf16 hh = (__bf16)v;
-    const float r1 = v - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+  for (int e = 0; e < 8; e += 2) {
+    bf16x2 hh, mm, ll;
+    split3_pair(e < 4 ? lo[e] : hi[e - 4], e < 4 ? lo[e + 1] : hi[e - 3], hh, mm, ll);       // (sr3_common.h)
+    h[e] = hh[0]; h[e + 1] = hh[1]; m[e] = mm[0]; m[e + 1] = mm[1]; l[e] = ll[0]; l[e + 1] = ll[1];
   }
 }
 }  // namespace

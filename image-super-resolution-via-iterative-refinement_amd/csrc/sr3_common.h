@@ -16,15 +16,41 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits): each residual is exact in fp32
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits): each residual is exact in fp32.  A pair at a time: one
+// v_cvt_pk_bf16_f32 per plane; the residual x - h of either element is one v_dot2c_f32_bf16 (acc += h.lo * -1 + h.hi * 0 and
+// the mirrored constant: the bf16 pair is consumed as it is, no unpack to fp32; the result is exactly representable, so the
+// instruction's internal rounding does not matter) -- 7 VALU instructions per pair instead of 9 (-DSR3_SPLIT_NO_DOT2: the
+// and / shift / packed-subtract form, A/B builds)
+__device__ __forceinline__ void split3_pair(float x0, float x1, bf16x2& h, bf16x2& m, bf16x2& l) {
+#ifdef SR3_SPLIT_NO_DOT2
+  h[0] = (__bf16)x0; h[1] = (__bf16)x1;
+  const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+  m[0] = (__bf16)r0; m[1] = (__bf16)r1;
+  const float q0 = r0 - (float)m[0], q1 = r1 - (float)m[1];
+  l[0] = (__bf16)q0; l[1] = (__bf16)q1;
+#else
+  // the selectors (-1, 0) / (0, -1) live in registers: as compile-time constants the compiler folds them into the inline
+  // constant -1.0, which this instruction reads as 0xBF800000 = (0, -1) for BOTH (measured: garbage results)
+  unsigned s_lo = 0x0000BF80u, s_hi = 0xBF800000u;
+  asm("" : "+v"(s_lo), "+v"(s_hi));              // (not volatile: one materialisation per kernel, hoisted out of the loops)
+  const bf16x2 sel_lo = __builtin_bit_cast(bf16x2, s_lo), sel_hi = __builtin_bit_cast(bf16x2, s_hi);
+  h[0] = (__bf16)x0; h[1] = (__bf16)x1;
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(h, sel_lo, x0, false);
+  const float r1 = __builtin_amdgcn_fdot2_f32_bf16(h, sel_hi, x1, false);
+  m[0] = (__bf16)r0; m[1] = (__bf16)r1;
+  const float q0 = __builtin_amdgcn_fdot2_f32_bf16(m, sel_lo, r0, false);
+  const float q1 = __builtin_amdgcn_fdot2_f32_bf16(m, sel_hi, r1, false);
+  l[0] = (__bf16)q0; l[1] = (__bf16)q1;
+#endif
+}
 __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const __bf16 hh = (__bf16)v[e];
-    const float r1 = v[e] - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+  for (int e = 0; e < 4; e += 2) {
+    bf16x2 hh, mm, ll;
+    split3_pair(v[e], v[e + 1], hh, mm, ll);
+    h[e] = hh[0]; h[e + 1] = hh[1]; m[e] = mm[0]; m[e + 1] = mm[1]; l[e] = ll[0]; l[e + 1] = ll[1];
   }
 }
 

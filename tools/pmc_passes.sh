@@ -1,13 +1,15 @@
 #!/bin/bash
 # The three counter passes of tools/round_profile.sh on their own (FETCH_SIZE, WRITE_SIZE, SQ set; each its own run, --kernel-trace only):
-#   bash tools/pmc_passes.sh <tag>      (through gpurun; writes gpurun_out/<tag>/{fetch,write,sq} + the summaries of pmc_traffic.py / pmc_sq.py)
+#   bash tools/pmc_passes.sh <tag> [extra bench.py flags, e.g. --exact-fp32]      (through gpurun; writes gpurun_out/<tag>/{fetch,write,sq} + the summaries of pmc_traffic.py / pmc_sq.py)
 set -u
 TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
-Q="--no-cpu-baseline --no-torch-baseline --train-steps 0 --no-split-leg --no-other-configs --no-exact-leg --no-roofline"
+shift || true
+Q="--no-cpu-baseline --no-torch-baseline --train-steps 0 --no-split-leg --no-other-configs --no-exact-leg --no-roofline $*"
 for attempt in 1 2; do
+  rm -rf $OUT/fetch
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python bench.py --steps 4 --warmup 1 $Q > /dev/null 2> $OUT/fetch.err && break
   echo "fetch pass attempt $attempt failed"; tail -3 $OUT/fetch.err | cut -c1-200
 done

@@ -17,11 +17,10 @@ python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 Q="--no-cpu-baseline --no-torch-baseline --train-steps 0 --no-split-leg --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 200 --warmup 5 $Q > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -o bench -- python bench.py --steps 4 --warmup 1 --no-roofline $Q > /dev/null 2> $OUT/sq.err
-python tools/pmc_traffic.py $OUT/fetch $OUT/write $OUT/$TAG > $OUT/pmc.log 2>&1
-python tools/pmc_sq.py $OUT/sq $OUT/$TAG >> $OUT/pmc.log 2>&1
+# counter passes (FETCH_SIZE, WRITE_SIZE, SQ set -- each its own run, --kernel-trace only; retried once: rocprofv3 --pmc has segfaulted
+# right after HSA initialisation on some boxes of the pool), then the same for the all-fp32-MFMA plan
+bash tools/pmc_passes.sh $TAG
+bash tools/pmc_passes.sh ${TAG}_exact_fp32 --exact-fp32
 python tools/op_table.py > $OUT/op_table.txt 2> $OUT/op_table.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- python tools/gpu_probe.py --train 64 > $OUT/train_probe.log 2>&1
 # stock PyTorch-ROCm: first run fills MIOpen's user find-db, the profiled second run reuses it
