@@ -1,5 +1,10 @@
 // Winograd F(2x2, 3x3) on the bf16 MFMA with 3-way split operands, FOUR waves of 512 registers (one per SIMD).
 //
+// EXPERIMENT, off by default (plan option wino4 / tile_cfg 13): parity-green, and no faster than the 8-wave SPLIT instantiation it was
+// meant to replace (8.01-8.4 vs 8.08 ms per step, profiles/r04e_wino4_ablations.txt).  The premise below -- that interleaving the
+// staging / transform VALU work with the MFMAs inside one wave hides it -- does not hold on gfx950: VALU instructions do not execute
+// next to an MFMA, whichever wave issues them (profiles/r04g_mfma_overlap_bf16.txt); the loop is 96 MFMAs + ~700 VALU in any order.
+//
 // Same op, same arithmetic and same derived filters as the SPLIT instantiation of conv3x3_wino.hip (plan option wino_split:
 // every fp32 operand as x = h + m + l, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation); what changes is
 // who owns what.  The 8-wave kernel gives a wave two positions of the 4x4 transform domain and 256 registers, which leaves

@@ -13,14 +13,16 @@
 // (the lane's 4 consecutive k; lanes 0-31 / 32-63 take k-quads 0 / 1 of each 8-k group, which
 // is a permutation of the k order shared by A and B, so the sum is unchanged).
 // Block = 256 threads = 2x2 waves, tile BM x BN, k-step 32 channels of one filter tap,
-// double-buffered LDS with register staging (global -> VGPR -> [GN/SiLU] -> LDS), one barrier
-// per k-step.  Split-K writes fp32 slabs that a second kernel reduces (deterministic).
+// double-buffered LDS with register staging (global -> VGPR -> [GN/SiLU] -> LDS; the global loads
+// run two k-steps ahead in two register sets), one barrier per k-step.  Split-K writes fp32 slabs
+// that a second kernel reduces (deterministic).
 //
 // SPLIT instantiations (ConvParams::igemm_split; plan option `gemm_split`): the same loader, prologue and epilogue on the
 // bf16 matrix pipe without losing bits -- every fp32 operand is written to LDS as three bf16 planes (x = h + m + l, 8 + 8 + 8
 // significant bits, each residual exact in fp32) while it is staged, and a product is the six v_mfma_f32_32x32x16_bf16
 // products hh + hm + mh + mm + hl + lh with fp32 accumulation (dropped terms <= 2^-24 of a product): 6/16 of the fp32
-// instruction's matrix-pipe time, and -- unlike the fp32 MFMA -- it runs beside the staging VALU work.  LDS rows are 32 bf16
+// instruction's matrix-pipe time (the split's VALU work is paid beside it in full: VALU instructions do not execute next to an
+// MFMA on gfx950, profiles/r04g_mfma_overlap_bf16.txt).  LDS rows are 32 bf16
 // (64 bytes, no padding), their four 16-byte segments XOR-swizzled with (row >> 2) & 3 (conv3x3_halo.hip's MODE 1 layout:
 // 8-byte staging writes and 16-byte fragment reads both conflict-free).  The 128 x 128 tile single-buffers its 48 KB stage
 // (two workgroups per CU; the second barrier of a k-step is covered by the other workgroup), the smaller tiles double-buffer.

@@ -101,7 +101,6 @@ struct sr3_plan {
   int fin_cin = 0, out_ch = 0;
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
-                             // 68 TF vs 72 TF for the im2col kernel's 64x64 tile on this network's layers, so off by default
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
   int wino4 = 0;             // wino_split convs on the four-wave, 512-register kernel (conv3x3_wino4.hip) where it applies
   int wino_split = 1;        // ... on its 3 x bf16 split instantiation (bf16 MFMA, fp32-class results; gated by tests/: error not
