@@ -91,7 +91,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "gemm_split", "wino4", "loss_l2"};
+ * "wino_split", "gemm_split", "gemm_tile", "wino4", "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
  *   split instantiation: every fp32 operand as x = h + m + l (three bf16 terms, each residual exact in fp32), every product as
@@ -102,6 +102,8 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  * gemm_split (default 1): the same 3 x bf16 split arithmetic for the convolutions of the im2col kernel (every 1x1 conv --
  *   res_conv, attention qkv / out -- and the stride-2 Downsample convs), operands split while they are staged into LDS.
  *   0: v_mfma_f32_32x32x2_f32.
+ * gemm_tile (default 0 = automatic; A/B runs): force im2col tile 1-4 (128x128 / 128x64 / 64x64 / 64x128) on every convolution of that
+ *   kernel -- how profiles/r04f_gemm_split_sweep.txt timed the tiles inside the forward.
  * wino4 (default 0, experimental): wino_split convolutions on the four-wave, 512-register kernel (conv3x3_wino4.hip).
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
