@@ -138,3 +138,32 @@ def test_bench_configs_are_the_reference_json_configs(name):
     assert got['diffusion']['conditional'] == ref['diffusion']['conditional'] == c['conditional']
     full = json.loads(txt)
     assert abs(full['train']['optimizer']['lr'] - c['lr']) < 1e-12
+
+
+def test_committed_profile_summaries_cover_the_kernels_bench_reports():
+    """bench.py's `roofline.traffic` / `sq_counters` come from the committed rocprofv3 counter summaries of the round, looked up by
+    the exact symbol of the dominant kernel: both plans the bench line reports (default: the split Winograd instantiation;
+    `exact_fp32`: the fp32-MFMA one) must be in them, with sane values, or those fields silently turn null."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_hbm_traffic.json')) as f:
+        traffic = json.load(f)
+    with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_sq_counters.json')) as f:
+        sq = json.load(f)
+    for sym in ('sr3::k_conv3x3_wino<0, false, false, true>', 'sr3::k_conv3x3_wino<0, false, false, false>',
+                'sr3::k_conv_igemm<64, 64, 1, true>', 'sr3::k_conv_igemm<64, 64, 1, false>'):
+        assert 2e7 < traffic[sym]['hbm_bytes_per_launch'] < 1e9, (sym, traffic.get(sym))
+        assert 0.05 < sq[sym]['mfma_busy'] < 1.0, (sym, sq.get(sym))
+    # the stats file the bench line's avg launch time must agree with
+    with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_bench_kernel_stats.csv')) as f:
+        head = f.read(4000)
+    assert 'k_conv3x3_wino<0, false, false, true>' in head
+    with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_bench.json')) as f:
+        line = json.loads(f.read().strip().splitlines()[-1])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and r['traffic'] and r['unit'] == 'TFLOP/s'
+    assert abs(line['value'] - 16 / (2000 * line['ms_per_step'] * 1e-3)) < 1e-9 * line['value'] + 1e-12
+    assert line['cpu_baseline']['kind'] in ('port', 'reference') and line['cpu_baseline']['cores'] >= 1
