@@ -43,7 +43,12 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-PROFILE_ROUND = 'r04'              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
+PROFILE_ROUND = 'r04'
+# sr3_unet_forward_profile op kinds (plan.hip): Winograd fp32 one-image / four-image tile, SPLIT one-image / four-image tile,
+# four-wave SPLIT kernel; im2col SPLIT tiles 14-17
+WINO_KINDS = (455, 465, 555, 565, 575)
+WINO_SPLIT_KINDS = (555, 565, 575)
+IGEMM_SPLIT_KINDS = (651, 652, 653, 654)              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
 
 # The `model` subtrees of the reference's configs (config/sr_sr3_16_128.json:39-77, sr_sr3_64_512.json:39-80,
 # sample_ddpm_128.json:38-79) + the batch sizes BASELINE.json quotes.
@@ -336,7 +341,8 @@ def roofline_from_profile(netG, x, cond, reps=3):
              156: 'k_conv3x3_halo<4,2,false,false,1,1>', 158: 'k_conv3x3_halo<4,2,true,false,1,1>',
              355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
              455: 'k_conv3x3_wino<0,false,false,false>', 465: 'k_conv3x3_wino<0,false,true,false>',
-             555: 'k_conv3x3_wino<0,false,false,true>'}
+             555: 'k_conv3x3_wino<0,false,false,true>', 565: 'k_conv3x3_wino<0,false,true,true>',
+             575: 'k_conv3x3_wino4<0,false>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -365,8 +371,8 @@ def roofline_from_profile(netG, x, cond, reps=3):
         counters = {'dominant_kernel': by_kernel(sq), 'attention': sq.get('attention')}
     except (OSError, ValueError):
         pass
-    is_wino = dom in (455, 465, 555)
-    is_split = dom == 555 or ((not is_wino) and names[dom].split(',')[4] == '1')
+    is_wino = dom in WINO_KINDS
+    is_split = dom in WINO_SPLIT_KINDS or ((not is_wino) and names[dom].split(',')[4] == '1')
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS
     # Winograd F(2x2,3x3): 16 multiplies per 2x2 output block and (cin, cout) pair instead of 36, so the MFMA pipe executes
@@ -374,18 +380,20 @@ def roofline_from_profile(netG, x, cond, reps=3):
     # fp32 MFMA roof (a fraction of a roof, <= 1); the direct-convolution-equivalent rate is reported beside it.
     executed = achieved / 2.25 if is_wino else achieved
     # step level: the floor the design chose = (Winograd FLOPs / 2.25 + all other contraction FLOPs) / peak
-    wino_fl = sum(agg[k][1] for k in (455, 465, 555) if k in agg) / reps
+    wino_fl = sum(agg[k][1] for k in WINO_KINDS if k in agg) / reps
     all_fl = sum(a[1] for a in agg.values()) / reps
-    # (the 3 x bf16 split kernels' share at their own roof, everything else at the fp32 MFMA roof)
-    split_fl = (agg[555][1] / reps if 555 in agg else 0.0)
-    floor_ms = ((wino_fl - split_fl) / 2.25 + (all_fl - wino_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3 + \
-               (split_fl / 2.25) / (BF16_MFMA_PEAK_TFLOPS / 6.0 * 1e12) * 1e3
+    # the 3 x bf16 split kernels' share at their own roof (bf16 peak / 6): the Winograd SPLIT instantiations (their FLOPs / 2.25)
+    # and the im2col SPLIT tiles (kinds 651-654: direct multiplies, no / 2.25); everything else at the fp32 MFMA roof
+    wsplit_fl = sum(agg[k][1] for k in WINO_SPLIT_KINDS if k in agg) / reps
+    gsplit_fl = sum(agg[k][1] for k in IGEMM_SPLIT_KINDS if k in agg) / reps
+    floor_ms = ((wino_fl - wsplit_fl) / 2.25 + (all_fl - wino_fl - gsplit_fl)) / (FP32_MFMA_PEAK_TFLOPS * 1e12) * 1e3 + \
+               (wsplit_fl / 2.25 + gsplit_fl) / (BF16_MFMA_PEAK_TFLOPS / 6.0 * 1e12) * 1e3
     # algorithmic HBM bytes of the dominant kernel's launches (each input / residual / output tensor and the transformed
     # filters once per launch), from the plan's own launch list
     alg_bytes = None
     try:
-        ops = [o for o in plan.op_list(B) if o['kind'] == 50 and o['tile_cfg'] == {455: 11, 465: 11, 555: 12}[dom]
-               and (o['h_out'] == 8) == (dom == 465)] if is_wino else []
+        ops = [o for o in plan.op_list(B) if o['kind'] == 50 and o['tile_cfg'] == {455: 11, 465: 11, 555: 12, 565: 12, 575: 13}[dom]
+               and (o['h_out'] == 8) == (dom in (465, 565))] if is_wino else []
         if ops:
             tot = 0.0
             for o in ops:
@@ -419,7 +427,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
                 all_halo_kernels_tflops=all_tf, sq_counters=counters, by_op_kind=detail)
 
 
-def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, restore=0, with_roofline=False):
+def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, restore=None, with_roofline=False):
     """Secondary, NOT the headline: the same reverse step with an opt-in plan option that moves contractions onto
     v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (six products, fp32 accumulate):
     `split_bf16` (round 1: the direct halo-tile convs with Cout > 64) or `wino_split` (round 4: the Winograd kernel's SPLIT
@@ -434,8 +442,9 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, re
     tm = torch.full((B, 1), 0.6, device=dev) if un.variant == 'sr3' else torch.full((B,), 900, dtype=torch.long, device=dev)
     eps_exact = un(x, tm, cond=cond).clone()         # (the plan the headline ran on)
     options = list(option) if isinstance(option, (list, tuple)) else [option]
-    for o in options:
-        un.plan.set_option(o, value)
+    # set_option returns the option's previous value: the leg puts back exactly what the headline plan ran with (an A/B run's
+    # --plan-opt included), not a constant
+    previous = {o: un.plan.set_option(o, value) for o in options}
     roof = None
     try:
         eps_split = un(x, tm, cond=cond).clone()
@@ -458,7 +467,7 @@ def split_bf16_leg(netG, st, T, dev, steps=200, option='split_bf16', value=1, re
             roof = roofline_from_profile(netG, st2['img'], st2['cond'])
     finally:
         for o in options:
-            un.plan.set_option(o, restore)
+            un.plan.set_option(o, previous[o] if restore is None else restore)
         netG._loop_cache = {}
     fl = un.plan.forward_flops(B)
     return dict(ms_per_step=ms, images_per_s_per_gpu=B / (T * ms * 1e-3), step_tflops_equiv=fl / (ms * 1e-3) / 1e12,
@@ -766,7 +775,7 @@ def main():
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and not a.no_exact_leg and not a.split_bf16 and not a.exact_fp32:
         try:       # the same step with every conv on the exact-fp32 MFMA instantiations (plan options wino_split = gemm_split = 0)
-            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option=('wino_split', 'gemm_split'), value=0, restore=1,
+            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option=('wino_split', 'gemm_split'), value=0,
                                                with_roofline=not a.no_roofline)
             rec['exact_fp32']['dtype'] = 'f32 (v_mfma_f32_32x32x2_f32 everywhere)'
         except Exception as e:                     # the secondary leg must never cost the headline line

@@ -39,6 +39,9 @@
 
 #include "sr3_common.h"
 
+#ifndef SR3_WINO_PRE
+#define SR3_WINO_PRE 0
+#endif
 #ifdef SR3_SPLIT_NOSB
 #define SR3_SB() do {} while (0)
 #else
@@ -665,6 +668,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       //   barrier ; stage chunk i + 2
       //   MFMA (m1, a) x 12 | U pos a of chunk i + 1 ; reads kk0 (m0 of chunk i + 1), finish ; fetch V_b (m1)
       //   MFMA (m1, b) x 12 | U pos b of chunk i + 1 ; reads kk1, finish ; park V_b (m0, i + 1) ; split -> V_a (m0, i + 1)
+      constexpr int PRE = DROP ? 0 : SR3_WINO_PRE;       // (the dropout instantiation has no registers for the early reads)
       bf16x8 vsa[3], vsb[3];
       f32x4 va0 = {0.f, 0.f, 0.f, 0.f}, vb0 = va0, va1 = va0, vb1 = va0;
       auto sp3 = [&](const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
@@ -716,16 +720,22 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         const float* rnext = (i & 1) ? raw0 : raw1;
         const bool more = i + 1 < nck;
         f32x4 da[3], db[3];
+        // SR3_WINO_PRE & 1 (round 5): the six row reads of the next half-unit are issued BEFORE the MFMA group and consumed behind
+        // it, so their LDS latency runs under the group (plain LDS traffic hides beside an MFMA: tools/mfma_fillers.hip); the
+        // first half of the iteration has the registers for it (0 spills), the second half -- staging loads in flight -- has not
+        if (PRE & 1) t_load(rcur, 1, 0, da, db);
+        SR3_SB();
         mfma_split(0, 0, vsa);
         SR3_SB();
-        t_load(rcur, 1, 0, da, db);
+        if (!(PRE & 1)) t_load(rcur, 1, 0, da, db);
         t_finish(da, db, va0, vb0);
-        SR3_SB();
+        if (!(PRE & 1)) SR3_SB();
         fetch_b();
+        if (PRE & 1) t_load(rcur, 1, 1, da, db);
         SR3_SB();
         mfma_split(0, 1, vsb);
         SR3_SB();
-        t_load(rcur, 1, 1, da, db);
+        if (!(PRE & 1)) t_load(rcur, 1, 1, da, db);
         t_finish(da, db, va1, vb1);
         SR3_SB();
         park_b();

@@ -39,8 +39,12 @@ __device__ __forceinline__ float silu_f(float v) {
   return SR3_SILU(v);
 }
 
-template <int BM, int BN, int TAPS, bool SPLIT>
+// SPLIT: 0 = fp32 MFMA, 1 = 3 x bf16 split with both operands split while staged, 2 = the same with the WEIGHTS pre-split
+// (ConvParams::w_split: three bf16 quads per weight quad, written once per weight change by igemm_split_weights -- a plan keeps
+// them in its derived buffer): every workgroup then splits only its activation rows, half of the split's VALU work
+template <int BM, int BN, int TAPS, int SPLITM>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
+  constexpr bool SPLIT = SPLITM != 0, WPRE = SPLITM == 2;
   constexpr int BK = 32, LDK = 36, LDB = 32;
   constexpr int NST = (SPLIT && BM + BN > 192) ? 1 : 2;      // LDS stages (single-stage on the 64x64 split tile too: 7.988 vs 7.985 ms per step, no gain)
   constexpr int AR = BM / 32, BR = BN / 32;  // loader rows per thread
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   // compute + stage phase to land even when the operands are cold (weights straight from HBM inside a forward; the split
   // instantiations' k-steps are ~1/3 as long as the fp32 ones: with one step of prefetch they were 14-40 % slower inside the
   // forward than in isolation, profiles/r04f_gemm_split_sweep.txt)
-  f32x4 ra[2][AR], rw[2][BR], ssa[AR], ssb[AR];       // (the GroupNorm pairs, L2-hot, stay one step ahead: one set)
+  f32x4 ra[2][AR], rw[2][WPRE ? 1 : BR], ssa[AR], ssb[AR];       // (the GroupNorm pairs, L2-hot, stay one step ahead: one set)
+  bf16x4 rws[2][WPRE ? BR : 1][3];                               // WPRE: the three planes of a weight quad as they are stored
   bool aok[2][AR], wok[2][BR];
   int aoff[2][AR];          // element offset of the staged quad (dropout mask index)
   using SET0 = std::integral_constant<int, 0>;
@@ -129,7 +134,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
       const bool ok = cvalid && n < p.Cout;
       wok[S][j] = ok;
       const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
-      rw[S][j] = *reinterpret_cast<const f32x4*>(p.w + off);
+      if constexpr (WPRE) {
+        const bf16x4* q = reinterpret_cast<const bf16x4*>(p.w_split) + (size_t)(off >> 2) * 3;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rws[S][j][pl] = q[pl];
+      } else {
+        rw[S][j] = *reinterpret_cast<const f32x4*>(p.w + off);
+      }
     }
   };
   auto load_ss = [&](int it) {       // scale / shift pairs of the k-step that is staged next
@@ -181,11 +192,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const f32x4 v = wok[S][j] ? rw[S][j] : zero;
+      const f32x4 v = WPRE ? zero : (wok[S][j] ? rw[S][WPRE ? 0 : j] : zero);
       if constexpr (SPLIT) {
         __bf16* Bb = reinterpret_cast<__bf16*>(A) + 3 * BM * LDB;     // planes [3][BN][LDB]
         bf16x4 h, m, l;
-        split3(v, h, m, l);
+        if constexpr (WPRE) {
+          const bf16x4 zb = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          h = wok[S][j] ? rws[S][j][0] : zb; m = wok[S][j] ? rws[S][j][1] : zb; l = wok[S][j] ? rws[S][j][2] : zb;
+        } else {
+          split3(v, h, m, l);
+        }
         const int o = swz(lrow + 32 * j, kq >> 1) + (kq & 1) * 4;
         *reinterpret_cast<bf16x4*>(&Bb[o]) = h;
         *reinterpret_cast<bf16x4*>(&Bb[BN * LDB + o]) = m;
@@ -381,6 +397,30 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
   }
 }
 
+// ---- pre-split weights of the SPLIT instantiations (ConvParams::w_split) --------------------------------------------------------
+// out[quad q][plane 3][4] bf16 with q = (OHWI element index) / 4: the three bf16 terms of the four weights of a channel quad next
+// to each other (24 bytes), so the loader's three 8-byte loads of a quad are one contiguous 24-byte run
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, long nquads, __bf16* __restrict__ out) {
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + q * 4);
+    bf16x4 h, m, l;
+    split3(v, h, m, l);
+    bf16x4* o = reinterpret_cast<bf16x4*>(out) + q * 3;
+    o[0] = h; o[1] = m; o[2] = l;
+  }
+}
+size_t igemm_wsplit_floats(size_t numel) { return ((numel / 4) * 6 + 3) & ~(size_t)3; }     // 24 bytes per quad, rounded to 16 bytes
+int igemm_split_weights(const float* w, size_t numel, float* out, hipStream_t st) {
+  if (numel & 3) { set_error("conv: weight count %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const long nq = (long)(numel / 4);
+  int blocks = (int)((nq + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, st, w, nq, reinterpret_cast<__bf16*>(out));
+  SR3_LAUNCH_CHECK("k_split_weights");
+  return SR3_OK;
+}
+
 // ---- host side --------------------------------------------------------------------------------
 namespace {
 struct TileCfg { int bm, bn; };
@@ -388,7 +428,7 @@ const TileCfg kCfgs[5] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-template <int BM, int BN, int TAPS, bool SPLIT = false>
+template <int BM, int BN, int TAPS, int SPLIT = 0>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
   constexpr int smem = SPLIT ? ((BM + BN > 192) ? 1 : 2) * (BM + BN) * 192 : 2 * (BM + BN) * 36 * 4;
@@ -560,11 +600,18 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
     if ((long)(ksplit - 1) * cdiv(nchunks, ksplit) >= nchunks && ksplit > 1) { set_error("conv: ksplit %d leaves an empty split over %d chunks", ksplit, nchunks); return SR3_E_BADARG; }
     rc = conv3x3_halo_forward(p, tile_cfg, g, st);
   } else
+  if (p.igemm_split && p.w_split) switch (tile_cfg) {
+    case 1: rc = k3 ? launch_conv<128, 128, 9, 2>(p, st) : launch_conv<128, 128, 1, 2>(p, st); break;
+    case 2: rc = k3 ? launch_conv<128, 64, 9, 2>(p, st) : launch_conv<128, 64, 1, 2>(p, st); break;
+    case 3: rc = k3 ? launch_conv<64, 64, 9, 2>(p, st) : launch_conv<64, 64, 1, 2>(p, st); break;
+    case 4: rc = k3 ? launch_conv<64, 128, 9, 2>(p, st) : launch_conv<64, 128, 1, 2>(p, st); break;
+    default: set_error("conv: bad tile_cfg %d", tile_cfg); return SR3_E_BADARG;
+  } else
   if (p.igemm_split) switch (tile_cfg) {
-    case 1: rc = k3 ? launch_conv<128, 128, 9, true>(p, st) : launch_conv<128, 128, 1, true>(p, st); break;
-    case 2: rc = k3 ? launch_conv<128, 64, 9, true>(p, st) : launch_conv<128, 64, 1, true>(p, st); break;
-    case 3: rc = k3 ? launch_conv<64, 64, 9, true>(p, st) : launch_conv<64, 64, 1, true>(p, st); break;
-    case 4: rc = k3 ? launch_conv<64, 128, 9, true>(p, st) : launch_conv<64, 128, 1, true>(p, st); break;
+    case 1: rc = k3 ? launch_conv<128, 128, 9, 1>(p, st) : launch_conv<128, 128, 1, 1>(p, st); break;
+    case 2: rc = k3 ? launch_conv<128, 64, 9, 1>(p, st) : launch_conv<128, 64, 1, 1>(p, st); break;
+    case 3: rc = k3 ? launch_conv<64, 64, 9, 1>(p, st) : launch_conv<64, 64, 1, 1>(p, st); break;
+    case 4: rc = k3 ? launch_conv<64, 128, 9, 1>(p, st) : launch_conv<64, 128, 1, 1>(p, st); break;
     default: set_error("conv: bad tile_cfg %d", tile_cfg); return SR3_E_BADARG;
   } else
   switch (tile_cfg) {

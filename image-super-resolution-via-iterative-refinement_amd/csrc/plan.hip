@@ -408,6 +408,9 @@ struct Builder {
       o.tile_cfg = P->gemm_tile; o.ksplit = P->ksplit;       // A/B knob: one im2col tile for every conv of that kernel
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
+    if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->wsplit_of.count(w)) {
+      o.has_wsplit = true; o.wsplit_off = P->wsplit_of[w];       // the SPLIT tile reads its weights pre-split from the derived buffer
+    }
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
       o.tile_cfg = 5; o.ksplit = P->ksplit;
       conv_pick(c, o.tile_cfg, o.ksplit);
@@ -616,6 +619,27 @@ void layout_derived(sr3_plan* P) {
       if (L.kind == 1) { reg(L.res.c1_w, L.res.cout, L.res.cin); reg(L.res.c2_w, L.res.cout, L.res.cout); }
       else if (L.kind == 3) reg(L.w, L.cout, L.cin);
     }
+  // the im2col SPLIT tiles' weights, pre-split (plan option gemm_split): res_conv and the attention projections (1x1), Downsample
+  // (3x3 stride 2; Cout <= 64 stays on the fp32 MFMA: Builder::conv)
+  P->wsplits.clear();
+  P->wsplit_of.clear();
+  if (P->gemm_split) {
+    auto regw = [&](size_t w, size_t numel) {
+      if (numel & 3) return;
+      P->wsplits.push_back({w, numel, dcur});
+      P->wsplit_of[w] = dcur;
+      dcur += igemm_wsplit_floats(numel);
+    };
+    for (auto* v : {&P->downs, &P->mid, &P->ups})
+      for (auto& L : *v) {
+        if (L.kind == 1) {
+          if (L.res.has_rc) regw(L.res.rc_w, (size_t)L.res.cout * L.res.cin);
+          if (L.res.attn) { regw(L.res.qkv_w, (size_t)3 * L.res.cout * L.res.cout); regw(L.res.ao_w, (size_t)L.res.cout * L.res.cout); }
+        } else if (L.kind == 2 && L.cout > 64) {
+          regw(L.w, (size_t)L.cout * 9 * L.cin);
+        }
+      }
+  }
   P->derived_floats = dcur;
   P->derived_from = nullptr;
   if (P->derived_bound_bytes < dcur * sizeof(float)) { P->derived_ptr = nullptr; P->derived_bound_bytes = 0; }   // re-bind a larger one
@@ -732,6 +756,13 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
             return SR3_E_BADARG;
           }
           c.wino_u = P->derived_ptr + o.wino_off;
+        }
+        if (o.has_wsplit && o.tile_cfg >= 1 && o.tile_cfg <= 4 && c.igemm_split) {
+          if (!P->derived_ptr || P->derived_from != params) {
+            set_error("the plan's derived (pre-split 1x1 / stride-2) weights are not bound or stale: call sr3_plan_bind_derived + sr3_plan_prepare_derived");
+            return SR3_E_BADARG;
+          }
+          c.w_split = P->derived_ptr + o.wsplit_off;
         }
         if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
         rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + R.scratch_off), R.scratch_bytes, st);
@@ -944,7 +975,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
   if (o.kind == OP_CONV) {
     const ConvParams& c = o.cp;
     out->tile_cfg = (o.tile_cfg == 11 && o.cp.wino_split) ? 11 + o.cp.wino_split
-                    : (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) ? 13 + o.tile_cfg : o.tile_cfg;
+                    : (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) ? (o.has_wsplit ? 17 : 13) + o.tile_cfg : o.tile_cfg;
     out->ksplit = o.ksplit;
     out->ksize = c.ksize; out->stride = c.stride; out->upsample = c.ups;
     out->cin = c.C0 + c.C1; out->cout = c.Cout; out->h_out = c.Ho; out->w_out = c.Wo;
@@ -988,7 +1019,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
-  if (slot == &plan->wino_split && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
+  if ((slot == &plan->wino_split || slot == &plan->gemm_split) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }
@@ -1031,6 +1062,10 @@ int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) 
                                   static_cast<hipStream_t>(stream), true);
       if (rc) return rc;
     }
+  }
+  for (const auto& d : plan->wsplits) {
+    const int rc = igemm_split_weights(params + d.w, d.numel, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
   }
   plan->derived_from = params;
   return SR3_OK;
@@ -1170,6 +1205,20 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   const bool wsplit = tile_cfg == 12 || tile_cfg == 13;     // tile 11 on the 3 x bf16 split instantiation (13: its four-wave form)
   if (wsplit) { c.wino_split = tile_cfg - 11; tile_cfg = 11; }
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }     // the im2col tiles 1-4 on their 3 x bf16 split instantiation
+  if (tile_cfg >= 18 && tile_cfg <= 21) {
+    // ... with the weights pre-split into bf16 planes (what a plan does, in its derived buffer): derived here, behind the split-K
+    // slabs in `scratch` (sr3_conv_scratch_bytes accounts for them)
+    c.igemm_split = 1; tile_cfg -= 17;
+    const size_t numel = (size_t)Cout * ksize * ksize * (c.C0 + c.C1);
+    const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
+    const size_t wb = igemm_wsplit_floats(numel) * sizeof(float);
+    if (!scratch || scratch_bytes < slab + wb) { set_error("conv: scratch too small for the pre-split weights (%zu < %zu)", scratch_bytes, slab + wb); return SR3_E_NOMEM; }
+    float* q = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
+    const int rc = igemm_split_weights(w, numel, q, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    c.w_split = q;
+    scratch_bytes = slab;
+  }
   if (tile_cfg == 11 && (ksize != 3 || stride != 1)) { set_error("conv: the Winograd kernel does not fit this problem (3x3 stride 1 only)"); return SR3_E_UNSUPPORTED; }
   if (tile_cfg == 11) {
     // Winograd form through the per-op entry: the transformed filters are derived here, behind the split-K slabs in
@@ -1255,12 +1304,17 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
     c.Hs = Ho; c.Ws = Wo; c.stride = 1;
     return conv_splitk_bytes(c, 11, ksplit) + wino_weight_floats(Cout, Cin, tile_cfg >= 12) * sizeof(float);
   }
+  size_t extra = 0;
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
+  if (tile_cfg >= 18 && tile_cfg <= 21) {      // + the pre-split weights behind the slabs
+    c.igemm_split = 1; tile_cfg -= 17;
+    extra = igemm_wsplit_floats((size_t)Cout * ksize * ksize * Cin) * sizeof(float);
+  }
   // the entry does not know the stride: take the larger of the stride-1 (halo kernel eligible) and the im2col sizing
   const size_t a = conv_splitk_bytes(c, tile_cfg, ksplit);
   c.Hs = Ho; c.Ws = Wo; c.stride = 1;
   const size_t b = conv_splitk_bytes(c, tile_cfg, ksplit);
-  return a > b ? a : b;
+  return (a > b ? a : b) + extra;
 }
 int sr3_groupnorm_stats_f32(const float* x, int B, int HW, int C, double* stat, void* stream) {
   if (!x || !stat) { set_error("null argument"); return SR3_E_BADARG; }
@@ -1274,6 +1328,7 @@ int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int
   c.Cout = Cout; c.C0 = Cin;
   if (tile_cfg == 12 || tile_cfg == 13) tile_cfg = 11;
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
+  if (tile_cfg >= 18 && tile_cfg <= 21) { c.igemm_split = 1; tile_cfg -= 17; }
   conv_pick(c, tile_cfg, ksplit);
   if (ksplit > 1) {
     const int rpb = splitk_rows_per_block(c, true);

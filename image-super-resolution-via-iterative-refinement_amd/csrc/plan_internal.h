@@ -57,6 +57,8 @@ struct Op {
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
   size_t wino_off = 0;             // tile_cfg 11: float offset of this conv's transformed filters in the derived buffer
+  bool has_wsplit = false;         // im2col SPLIT tile: its weights pre-split into bf16 planes sit in the derived buffer ...
+  size_t wsplit_off = 0;           // ... at this float offset (ConvParams::w_split)
 };
 
 struct Tap { std::string name; size_t off; int C, H, W; };
@@ -112,6 +114,10 @@ struct sr3_plan {
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;
   std::map<size_t, size_t> derived_of;     // weight arena offset -> float offset in the derived buffer
+  // ... and, plan option gemm_split, the 1x1 / stride-2 weights of the im2col SPLIT tiles as three bf16 planes (conv_igemm.hip)
+  struct WSplit { size_t w, numel, off; };
+  std::vector<WSplit> wsplits;
+  std::map<size_t, size_t> wsplit_of;      // weight arena offset -> float offset in the derived buffer
   size_t derived_floats = 0;
   float* derived_ptr = nullptr;
   size_t derived_bound_bytes = 0;

@@ -154,6 +154,8 @@ struct ConvParams {
   int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI);
                        // 2: the same filters on the four-wave kernel of conv3x3_wino4.hip (tile_cfg 13)
   int igemm_split;     // im2col kernel (tile_cfg 1-4; 1x1 and stride-2 convs): 1 = its 3 x bf16 split instantiation (tile_cfg 14-17 at the ABI)
+  const void* w_split; // igemm_split: the weights pre-split into bf16 planes by igemm_split_weights (tile_cfg 18-21 at the ABI; a plan
+                       // keeps them in its derived buffer); null: the kernel splits the weights while it stages them
 };
 
 __device__ __forceinline__ unsigned hash32(unsigned x) {
@@ -173,6 +175,9 @@ int conv_forward(const ConvParams& p, int tile_cfg, int ksplit, float* splitk_sc
 size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
 int splitk_rows_per_block(const ConvParams& p, bool stats);
+// pre-split weights of the im2col SPLIT instantiations: floats of the derived block for `numel` weights, and the transform
+size_t igemm_wsplit_floats(size_t numel);
+int igemm_split_weights(const float* w, size_t numel, float* out, hipStream_t st);
 // profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the
 // split-K reduce kernel (then resets the pointer).  Thread-local.
 void conv_set_mid_event(hipEvent_t ev);

@@ -235,8 +235,11 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * derived into `scratch` by this entry point); tile_cfg 12 = the same kernel's 3 x bf16 split instantiation (one-image tile
  * only; what plan option wino_split selects), 13 = its four-wave experimental form (plan option wino4); tile_cfg 1-4 = the
  * im2col kernel's 128x128 / 128x64 / 64x64 / 64x128 tiles on the exact-fp32 MFMA, 14-17 = the same tiles on the 3 x bf16 split
- * instantiation (what plan option gemm_split selects).
- * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11), sized by sr3_conv_scratch_bytes. */
+ * instantiation with both operands split while they are staged, 18-21 = the same with the weights pre-split into bf16 planes
+ * (what plan option gemm_split selects: a plan keeps the planes in its derived buffer; this entry point derives them into
+ * `scratch`; results are bit-identical to 14-17).
+ * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-21), sized by
+ * sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
                  int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,
                  int act, const float* film, int film_stride, const float* res0, int RC0, const float* res1,

@@ -174,13 +174,20 @@ def test_plan_launch_list_no_gpu():
         if o['tile_cfg'] == 11 and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
             assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
     nbytes_both = int(p.lib.sr3_plan_derived_bytes(p.handle))
+    # ... of which the pre-split 1x1 / stride-2 weights of the im2col SPLIT tiles (plan option gemm_split): three bf16 planes =
+    # 6 bytes per weight of the res_convs, attention projections and Downsample convs with Cout > 64
+    p.set_option('gemm_split', 0)
+    nbytes_wsplit = nbytes_both - int(p.lib.sr3_plan_derived_bytes(p.handle))
+    p.set_option('gemm_split', 1)
+    n_w = sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in wconvs if 18 <= o['tile_cfg'] <= 21)
+    assert nbytes_wsplit == 6 * n_w and int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_both
     p.set_option('wino_split', 0)                         # the exact-fp32 MFMA instantiation everywhere: same list, tile 11
     eops = p.op_list(16)
     assert len(eops) == len(wops)
     for a, b in zip(wops, eops):
         assert b['tile_cfg'] == (11 if a['tile_cfg'] == 12 else a['tile_cfg']) and a['ksplit'] == b['ksplit'] and a['flops'] == b['flops']
     # the derived buffer holds both forms of every filter under wino_split (fp32 + 1.5x that for the three bf16 planes)
-    assert abs(nbytes_both / int(p.lib.sr3_plan_derived_bytes(p.handle)) - 2.5) < 1e-6
+    assert abs((nbytes_both - nbytes_wsplit) / (int(p.lib.sr3_plan_derived_bytes(p.handle)) - nbytes_wsplit) - 2.5) < 1e-6
     p.set_option('wino_split', 1)
     # a batch that is not a multiple of 4 keeps the direct halo kernel on the 8x8 maps
     for o in p.op_list(3):
@@ -200,9 +207,10 @@ def test_plan_launch_list_no_gpu():
         halo = 5 <= o['tile_cfg'] <= 10
         assert halo == (o['ksize'] == 3 and o['stride'] == 1), o
         # 1x1 / stride-2 convs: the im2col kernel's 64x64 tile on its 3 x bf16 split instantiation (plan option gemm_split,
-        # default 1; reported as tile 16 = the split form of tile 3); the 9-tap Downsample with Cout <= 64 stays on the fp32 MFMA
+        # default 1; reported as tile 20 = the split form of tile 3 with pre-split weights from the derived buffer); the 9-tap
+        # Downsample with Cout <= 64 stays on the fp32 MFMA
         if not halo:
-            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 16), o
+            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 20), o
         if o['fused_res_conv_cin']:
             assert halo and not o['upsample']
     # 18 ResnetBlocks change their channel count: where block2's conv runs unsplit (the 128x128 and 64x64 levels) their
@@ -227,8 +235,8 @@ def test_plan_launch_list_no_gpu():
     p.set_option('gemm_split', 0)
     for a, b in zip(ops, p.op_list(16)):
         assert a['kind'] == b['kind'] and a['flops'] == b['flops']
-        if a['kind'] == 50 and 14 <= a['tile_cfg'] <= 17:
-            assert b['tile_cfg'] == a['tile_cfg'] - 13 == 3 and a['ksplit'] == b['ksplit'], (a, b)
+        if a['kind'] == 50 and 18 <= a['tile_cfg'] <= 21:
+            assert b['tile_cfg'] == a['tile_cfg'] - 17 == 3 and a['ksplit'] == b['ksplit'], (a, b)
         else:
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('gemm_split', 1)

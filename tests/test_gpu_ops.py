@@ -328,14 +328,15 @@ GEMM_SPLIT_CASES = [
 ]
 
 
-@pytest.mark.parametrize('tile,ksplit', [(14, 1), (15, 1), (16, 1), (17, 1), (15, 2), (0, 0)])
+@pytest.mark.parametrize('tile,ksplit', [(14, 1), (16, 1), (15, 2), (18, 1), (19, 1), (20, 1), (21, 1), (19, 2), (20, 3), (0, 0)])
 @pytest.mark.parametrize('case', GEMM_SPLIT_CASES, ids=[c[0] for c in GEMM_SPLIT_CASES])
 def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
     """Gate of the `gemm_split` plan option (tiles 14-17: the im2col kernel's 3 x bf16 split instantiations -- operands split
-    into h + m + l while they are staged, six bf16 MFMA products per term, fp32 accumulation): on the 1x1 / stride-2 layer
+    into h + m + l while they are staged, six bf16 MFMA products per term, fp32 accumulation; tiles 18-21: the same with the
+    weights pre-split into bf16 planes, which is what a plan runs): on the 1x1 / stride-2 layer
     shapes of the BASELINE networks the error against float64 is not above the exact-fp32 instantiation's (tile 3) on the
     same data, and the stated tolerance holds.  (0, 0) is the ABI's auto pick, which stays on the fp32 MFMA."""
-    if tile in (14, 17) and case[6] <= 64:
+    if tile in (14, 17, 18, 21) and case[6] <= 64:
         pytest.skip('128-wide tiles are not used for Cout <= 64')
     src0, src1, w, kw = _make_case(case, seed=11)
     ref = G.conv_ref(src0, src1, w, **kw)
@@ -353,6 +354,62 @@ def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
         return
     assert rms_s <= 1.1 * rms_f + 1e-9 * scale, (rms_s, rms_f)
     assert e_s <= 1.5 * e_f + 1e-8 * scale, (e_s, e_f)
+    if tile >= 18:      # pre-split weights are the same three bf16 terms the kernel would have built itself: identical results
+        same, _ = G.conv_call(src0, src1, w, tile_cfg=tile - 4, ksplit=ksplit, **kw)
+        assert torch.equal(got, same), 'pre-split weights changed the result'
+
+
+GEMM_STRESS_CASES = [
+    # name, B, C0, C1, H, W, Cout, ksize, stride, act, scale of the GroupNorm (scale, shift) pairs
+    ('stress_qkv_512to1536', 2, 512, 0, 16, 16, 1536, 1, 1, 1, 300.0),      # attention qkv: post-GroupNorm affine, no SiLU
+    ('stress_s2_512to512', 2, 512, 0, 16, 16, 512, 3, 2, 0, 1.0),           # Downsample: raw feature maps, K = 4608
+    ('stress_res_conv_768to256', 1, 512, 256, 32, 32, 256, 1, 1, 0, 1.0),   # res_conv over the skip concat
+]
+
+
+@pytest.mark.parametrize('tile', [3, 16, 18, 19, 20, 21], ids=['fp32', 'split_64x64', 'pre_128x128', 'pre_128x64', 'pre_64x64', 'pre_64x128'])
+@pytest.mark.parametrize('ksplit', [1, 2])
+@pytest.mark.parametrize('case', GEMM_STRESS_CASES, ids=[c[0] for c in GEMM_STRESS_CASES])
+def test_gemm_split_stress_absolute_bound(case, ksplit, tile):
+    """The im2col SPLIT tiles on data built to hurt them (the companion of test_winograd_conv_stress_absolute_bound): log-normal
+    heavy-tailed inputs up to ~1e3 with pixel-to-pixel sign flips, a few output / input channels of the filters 30x louder than
+    the rest, against an ABSOLUTE float64 criterion: every output within 4 gamma_K conv(|a|, |w|) of the float64 result,
+    K = ksize^2 Cin, gamma_K = K u / (1 - K u), u = 2^-24 -- the fp32-class claim of the headline dtype on every input, not
+    only on N(0, 1)-like data.  The fp32 MFMA tile runs the same case for the record."""
+    import torch.nn.functional as F
+    name, B, C0, C1, H, W, Cout, k, stride, act, amp = case
+    Cin = C0 + C1
+    g = torch.Generator().manual_seed(199)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x = x * torch.exp(1.5 * torch.randn(B, Cin, H, W, generator=g))
+    checker = ((torch.arange(H)[:, None] + torch.arange(W)[None, :]) % 2 * 2 - 1).float()
+    x[:, ::7] = x[:, ::7].abs() * checker
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(k * k * Cin)
+    w[::5] *= 30.0
+    w[:, ::11] *= 30.0
+    bias = torch.randn(Cout, generator=g)
+    kw = dict(ups=0, stride=stride, bias=bias)
+    a = x.double()
+    if act:
+        ss = torch.stack([torch.randn(B, Cin, generator=g) * amp, torch.randn(B, Cin, generator=g) * amp], dim=2).contiguous()
+        kw.update(act=act, ss=ss)
+        a = a * ss[:, :, 0].double()[:, :, None, None] + ss[:, :, 1].double()[:, :, None, None]
+        if act == 2:
+            a = a * torch.sigmoid(a)
+    src0, src1 = (x[:, :C0].contiguous(), x[:, C0:].contiguous()) if C1 else (x, None)
+    got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
+    ref = G.conv_ref(src0, src1, w, **kw)
+    mag = F.conv2d(a.abs(), w.double().abs(), None, stride=stride, padding=k // 2) + bias.double().abs()[None, :, None, None]
+    K = k * k * Cin
+    u = 2.0 ** -24
+    gamma = K * u / (1 - K * u)
+    err = (got.double() - ref).abs()
+    ratio = (err / (4 * gamma * mag + 1e-300)).max().item()
+    print('%s ks%d tile %d: |a|max %.3g, |ref|max %.3g, max err %.3g, rms err %.3g, max err / (4 gamma_K conv(|a|,|w|)) = %.3g'
+          % (name, ksplit, tile, a.abs().max().item(), ref.abs().max().item(), err.max().item(), err.pow(2).mean().sqrt().item(), ratio))
+    assert torch.isfinite(got).all()
+    assert a.abs().max().item() > 500.0                                      # the case really is a stress case
+    assert ratio <= 1.0, ratio
 
 
 @pytest.mark.parametrize('K', [(64, 0), (512, 0), (512, 512)], ids=['K576', 'K4608', 'K9216'])

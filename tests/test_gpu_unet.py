@@ -81,7 +81,7 @@ def test_unet_forward_exact_fp32_option(name):
     d = G.dev()
     x, t = torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d)
     assert un.plan.options.get('wino_split', 1) == 1 and un.plan.options.get('gemm_split', 1) == 1
-    split_tiles = (12, 14, 15, 16, 17)
+    split_tiles = (12, 14, 15, 16, 17, 18, 19, 20, 21)
     has_split = any(o['tile_cfg'] in split_tiles for o in un.plan.op_list(x.shape[0]))
     assert has_split, 'the default plan of %s has no conv on a split instantiation' % name
     e0 = un(x, t).clone()

@@ -16,7 +16,12 @@ KIND = {10: 'embed + FiLM rows', 20: 'input conv (NCHW -> NHWC)', 30: 'GroupNorm
         50: 'conv', 60: 'attention', 70: 'output block (NHWC -> NCHW)'}
 TILE = {1: 'im2col 128x128', 2: 'im2col 128x64', 3: 'im2col 64x64', 4: 'im2col 64x128', 5: 'halo 128x128', 6: 'halo 256x64',
         7: 'halo 128x128 split-bf16', 8: 'halo 256x64 split-bf16 (8 waves)', 9: 'halo 256x128 (8 waves)',
-        10: 'halo 256x128 split-bf16 (8 waves)', 11: 'Winograd F(2x2,3x3) 64 tiles x 64 (8 waves)'}
+        10: 'halo 256x128 split-bf16 (8 waves)', 11: 'Winograd F(2x2,3x3) 64 tiles x 64 (8 waves)',
+        12: 'Winograd F(2x2,3x3) 3 x bf16 split (8 waves)', 13: 'Winograd F(2x2,3x3) 3 x bf16 split (4 waves)',
+        14: 'im2col 128x128 3 x bf16 split', 15: 'im2col 128x64 3 x bf16 split', 16: 'im2col 64x64 3 x bf16 split',
+        17: 'im2col 64x128 3 x bf16 split', 18: 'im2col 128x128 3 x bf16 split, pre-split weights',
+        19: 'im2col 128x64 3 x bf16 split, pre-split weights', 20: 'im2col 64x64 3 x bf16 split, pre-split weights',
+        21: 'im2col 64x128 3 x bf16 split, pre-split weights'}
 
 
 def main():
@@ -36,7 +41,7 @@ def main():
         if o['kind'] == 50:
             d = '%dx%d%s %4d -> %4d @ %3dx%-3d  %-34s ksplit %d%s%s  %7.2f GFLOP' % (
                 o['ksize'], o['ksize'], ' s2' if o['stride'] == 2 else (' up' if o['upsample'] else '   '), o['cin'], o['cout'],
-                o['h_out'], o['w_out'], TILE[o['tile_cfg']], o['ksplit'],
+                o['h_out'], o['w_out'], TILE.get(o['tile_cfg'], str(o['tile_cfg'])), o['ksplit'],
                 ' +1x1 res_conv(%d)' % o['fused_res_conv_cin'] if o['fused_res_conv_cin'] else '',
                 ' +stats' if o['fused_output_stats'] else '', o['flops'] / 1e9)
         elif o['kind'] == 60:

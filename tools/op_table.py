@@ -12,7 +12,9 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 KIND = {10: 'embed+FiLM', 20: 'conv_in', 30: 'GN stats', 40: 'GN fold', 50: 'conv', 60: 'attention', 70: 'conv_out'}
 TILE = {1: 'im2col 128x128', 2: 'im2col 128x64', 3: 'im2col 64x64', 4: 'im2col 64x128', 5: 'halo 128x128', 6: 'halo 256x64',
         9: 'halo 256x128', 11: 'winograd', 12: 'winograd 3xbf16', 13: 'winograd 3xbf16 4w',
-        14: 'im2col 3xbf16 128x128', 15: 'im2col 3xbf16 128x64', 16: 'im2col 3xbf16 64x64', 17: 'im2col 3xbf16 64x128'}
+        14: 'im2col 3xbf16 128x128', 15: 'im2col 3xbf16 128x64', 16: 'im2col 3xbf16 64x64', 17: 'im2col 3xbf16 64x128',
+        18: 'im2col 3xbf16 128x128 presplit-w', 19: 'im2col 3xbf16 128x64 presplit-w', 20: 'im2col 3xbf16 64x64 presplit-w',
+        21: 'im2col 3xbf16 64x128 presplit-w'}
 
 
 def main():
