@@ -42,6 +42,22 @@
 #ifndef SR3_WINO_PRE
 #define SR3_WINO_PRE 0
 #endif
+#ifndef SR3_WINO_PARKB
+#define SR3_WINO_PARKB 1     // ping-pong loop: position b's transformed values wait in LDS between transform and split (A/B)
+#endif
+#ifndef SR3_PP_TOKEN
+#define SR3_PP_TOKEN 0       // ping-pong loop, relaxed form: MFMA clusters of a SIMD's two waves handed off through LDS counters (A/B)
+#endif
+#ifndef SR3_PP_STRICT
+#define SR3_PP_STRICT 0      // ping-pong loop: 1 = a workgroup barrier behind every cluster, 0 = one per chunk, staggered (A/B)
+#endif
+#ifndef SR3_PP_PREFETCH
+#define SR3_PP_PREFETCH 0    // ping-pong loop: LDS reads of a VALU cluster issued ahead of the MFMA cluster in front of it (A/B)
+#endif
+#ifndef SR3_WINO_PP
+#define SR3_WINO_PP 0        // SPLIT main loop: 0 = round 4's one-barrier-per-chunk loop; 1 = the clustered ("ping-pong") schedule of round 5, an
+                             // A/B build: parity-green, measured equal (relaxed) or slower (strict / hand-off / prefetch) -- DESIGN.md section 3.1e
+#endif
 #ifdef SR3_SPLIT_NOSB
 #define SR3_SB() do {} while (0)
 #else
@@ -86,7 +102,8 @@ constexpr int W_CST_F = 64 + W_MAX_CK * 2 * WCK;      // per-tile constants: bia
                                                       // during the epilogue
 static_assert(2 * W_RAW_F <= W_EXCH_F && W_RAW_F == WGeo<false>::RAW_F && 2 * WGeo<true>::RAW_F <= W_EXCH_F,
               "the raw tiles live inside the exchange block's footprint");
-constexpr int W_SMEM = (W_EXCH_F + 2 * W_CST_F) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
+constexpr int W_TOK_F = W_EXCH_F + 2 * W_CST_F;        // 8 hand-off counters of the SPLIT loop, behind the constants (the epilogue's exchange block must not touch them)
+constexpr int W_SMEM = (W_TOK_F + 8) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
 static_assert(W_SMEM <= 163840, "LDS");
 
 // x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e) and the hardware reciprocal: ~1e-7 relative error on silu,
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // and re-read (three 8-byte reads) right before every staging step of the loop; the next tile's values are computed into the
   // registers again in the epilogue
   int* ptab = reinterpret_cast<int*>(smem + 2 * GE::RAW_F);       // [item][thread] of (hinfo, hpix)
-  static_assert(2 * GE::RAW_F + 2 * WHI * WNT + 3 * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation");
+  static_assert(!SPLIT || NB4 || 2 * GE::RAW_F + 2 * WHI * WNT + (2 * WHI + 2) * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation");
   auto hinfo = [&](int j) { return hinfo_r[j]; };
   auto pixel_of = [&](int j) {                    // source pixel of staging item j of the current tile (-1: zero padding)
     const int hj = hinfo_r[j];
@@ -366,19 +383,41 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
 #pragma unroll
     for (int j = 0; j < WHI; ++j) reinterpret_cast<int2_t*>(ptab)[j * WNT + tid] = int2_t{hinfo_r[j], hpix[j]};
   };
-  auto fetch_items = [&]() {                       // SPLIT, main loop: LDS -> registers, right before a staging step
+  auto fetch_items = [&](int j0 = 0, int j1 = GE::WHI) {       // SPLIT, main loop: LDS -> registers, right before a staging step
     if (!SPLIT) return;
     int t_ = tid;
     asm volatile("" : "+v"(t_));
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
+      if (j < j0 || j >= j1) continue;
       const int2_t v = reinterpret_cast<const int2_t*>(ptab)[j * WNT + t_];
       hinfo_r[j] = v.x; hpix[j] = v.y;
     }
   };
   f32x4 rh[WHI];            // staging registers of the main loop (and of the tile's chunk 0)
   f32x4 rh2[WHI];           // ... of the tile's chunk 1: fetched during the previous tile's epilogue, idle in the main loop
-  auto load_raw = [&](int chunk, f32x4 (&r)[WHI]) {
+  auto load_raw = [&](int chunk, f32x4 (&r)[WHI], int j0 = 0, int j1 = GE::WHI) {
+    const int c = chunk * WCK + kq * 4;
+    const int ce = c < Cin ? c : 0;
+    const bool second = ce >= p.C0;
+    const float* sp_ = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) {
+      if (j < j0 || j >= j1) continue;
+      const int hp_ = hpx(j);
+      const int off = hp_ >= 0 ? hp_ * sC + cs : 0;
+      r[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
+    }
+  };
+  // SPLIT, ping-pong loop: the raw loads of the main loop land in LDS instead of registers (global_load_lds_dwordx4: lane l of a
+  // wave writes 16 bytes at M0 + 16 l) -- zone[item][thread], i.e. every thread later reads back exactly what its own lane
+  // fetched, so the only synchronisation is the issuing wave's vmcnt.  The compiler does not order a later ds_read behind the
+  // transfer (checked on this toolchain), so the consumer waits on an explicit vmcnt; twelve registers fewer across the loop,
+  // where the staging loads otherwise spill (a spill right behind a global load waits for it at once).
+  f32x4* zone = reinterpret_cast<f32x4*>(ptab + 2 * WHI * WNT);       // [item][thread], behind the parked staging items
+  auto dma_raw = [&](int chunk, int z) {        // all items of `chunk` into zone parity z
     const int c = chunk * WCK + kq * 4;
     const int ce = c < Cin ? c : 0;
     const bool second = ce >= p.C0;
@@ -389,16 +428,38 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     for (int j = 0; j < WHI; ++j) {
       const int hp_ = hpx(j);
       const int off = hp_ >= 0 ? hp_ * sC + cs : 0;
-      r[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp_ + off),
+                                       (__attribute__((address_space(3))) void*)(zone + (z * WHI + j) * WNT + wave * 64), 16, 0, 0);
+    }
+  };
+  auto zone_read = [&](f32x4 (&r)[WHI], int z, int j0 = 0, int j1 = GE::WHI) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+#pragma unroll
+    for (int j = 0; j < WHI; ++j) {
+      if (j < j0 || j >= j1) continue;
+      r[j] = zone[(z * WHI + j) * WNT + t_];
     }
   };
   // GroupNorm (scale, shift) of the tile's image for the channels of this workgroup's chunk range live in LDS (cst + 64 of the
   // tile's parity): the staging step reads its 4 channels' pairs from there instead of keeping 8 registers live across a chunk
-  auto store_raw = [&](float* raw, int chunk, const f32x4 (&r)[WHI], const float* cs_) {
+  auto load_pairs = [&](int chunk, const float* cs_, f32x4 (&ss)[2]) {       // (one-image tile) the staging step's pairs, read ahead
+    ss[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ss[1] = ss[0];
+    if (p.act != 0) {
+      int kq_ = kq;
+      asm volatile("" : "+v"(kq_));
+      const float* q = cs_ + 64 + (chunk - c_begin) * (2 * WCK) + kq_ * 8;
+      ss[0] = *reinterpret_cast<const f32x4*>(q);
+      ss[1] = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+  };
+  auto store_raw = [&](float* raw, int chunk, const f32x4 (&r)[WHI], const float* cs_, int j0 = 0, int j1 = GE::WHI,
+                       const f32x4* pss = nullptr) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const bool hvalid = chunk * WCK + kq * 4 < Cin;
     f32x4 ssa = zero, ssb = zero;
-    if (p.act != 0 && !NB4) {
+    if (pss) { ssa = pss[0]; ssb = pss[1]; }
+    else if (p.act != 0 && !NB4) {
       int kq_ = kq;
       asm volatile("" : "+v"(kq_));
       const float* q = cs_ + 64 + (chunk - c_begin) * (2 * WCK) + kq_ * 8;
@@ -407,6 +468,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     }
 #pragma unroll
     for (int j = 0; j < WHI; ++j) {
+      if (j < j0 || j >= j1) continue;
       if (lrow + (WNT / 4) * j < WHP) {
         f32x4 v = r[j];
         if (NB4 && p.act != 0) {                    // the pairs of THIS item's image: [image][chunk of the split][16 x 2]
@@ -540,11 +602,19 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   const __bf16* ubase_s = nullptr;
   auto load_us = [&](int chunk, int pj) {
     if ((DBG & 16) && chunk != c_begin) return;
-    const __bf16* q = ubase_s + (size_t)chunk * 16 * (2 * WUS) + pj * (2 * WUS);
+    // scalar base + 32-bit lane offset (the saddr form of the load): no 64-bit address pair lives across the loop
+    const char* q = reinterpret_cast<const char*>(ubase_s + (size_t)chunk * 16 * (2 * WUS) + pj * (2 * WUS));
+    unsigned l_ = (unsigned)lane;
+    asm volatile("" : "+v"(l_));
+    const unsigned vo = l_ * 16u;                  // zero-extended 32-bit lane offset: global_load ... v, s[base:base+1] offset:imm
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 2; ++n) {
+      const char* qn = q + n * (WUS * 2);          // (its own scalar base: the immediate offsets stay below 4 KB)
+      asm volatile("" : "+s"(qn));
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) us[pj][n][pl] = *reinterpret_cast<const bf16x8*>(q + n * WUS + pl * 512);
+      for (int pl = 0; pl < 3; ++pl)           // (explicitly global: behind the laundering the pointer would be a flat one)
+        us[pj][n][pl] = *(const __attribute__((address_space(1))) bf16x8*)(qn + (size_t)vo + pl * 1024);
+    }
   };
 
   f32x16 acc[2][2][2];          // [pj][mblk][nblk]
@@ -597,6 +667,9 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // static priority for the second-dispatched half of the workgroup (the arbitration loser on every SIMD)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
+  int gseq = 0;                                      // SPLIT ping-pong loop: MFMA clusters this wave has issued (kernel lifetime)
+  if (SPLIT && SR3_WINO_PP && SR3_PP_TOKEN && tid < 8)
+    reinterpret_cast<int*>(smem + W_TOK_F)[tid] = 0;       // (the first barrier below)
   // ---- first tile: constants, raw chunks 0 and 1 ------------------------------------------------------------------
   int vtile = blockIdx.x;
   int par = 0;                                       // parity of the tile: which half of the constants block it uses
@@ -624,7 +697,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       int l_ = lane;
       asm volatile("" : "+v"(l_));
       ubase = ufrag + (size_t)cb * nch * 16 * 1024 + (size_t)(wi * 4 + wh * 2) * 1024 + l_ * 4;
-      ubase_s = reinterpret_cast<const __bf16*>(ufrag) + (size_t)cb * nch * 16 * (2 * WUS) + (size_t)(wi * 4 + wh * 2) * (2 * WUS) + l_ * 8;
+      ubase_s = reinterpret_cast<const __bf16*>(ufrag) + (size_t)cb * nch * 16 * (2 * WUS) + (size_t)(wi * 4 + wh * 2) * (2 * WUS);     // (wave-uniform)
     }
     if (SPLIT) {
       load_us(c_begin, 0);
@@ -644,7 +717,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     park_items();
     store_raw(raw0, c_begin, rh, cs_);
     if (nck > 1) store_raw(raw1, c_begin + 1, rh2, cs_);
-    load_raw(c2, rh);
+    if (SPLIT && SR3_WINO_PP) dma_raw(c2, 0); else load_raw(c2, rh);
     __syncthreads();
     stamp(vtile, 1);
 
@@ -680,6 +753,175 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         }
         split3x8(lo, hi, h, m, l);
       };
+#if SR3_WINO_PP
+      // ---- ping-pong schedule (round 5) --------------------------------------------------------------------------------------
+      // What tools/mfma_fillers.hip measured on gfx950 (profiles/r05c_mfma_fillers.txt): plain VALU work of one wave of a SIMD runs
+      // under the MFMAs of the OTHER wave for free (two waves per SIMD in anti-phase: up to 5 VALU per MFMA cost nothing; with an
+      // s_barrier behind every cluster as the metronome the pair even beats the bare two-wave MFMA stream), while two waves in
+      // lock step -- what one barrier per chunk gives, and what this loop did until round 4 -- add their MFMA and VALU times
+      // (measured then: 7.1 k cycles per chunk against 3.07 k of MFMAs).  So the loop is cut into clusters, MFMA (G: the 12 MFMAs
+      // of one position of one tile block) and VALU (V), a workgroup barrier behind each, and waves 4-7 (the second wave of every
+      // SIMD) run one barrier behind waves 0-3: whenever one wave of a SIMD is in a G cluster the other is in a V cluster.
+      //   G1 (m0, a) | V1: split b (m0) ; transform m1               | G2 (m0, b) | V2: split a (m1) ; stage chunk i + 2
+      //   G3 (m1, a) | V3: split b (m1) ; transform m0 of chunk i + 1 | G4 (m1, b) | V4: split a (m0 of chunk i + 1)
+      // The barriers are also the only synchronisation the raw tiles need: with waves 4-7 one slot late, the last reads of
+      // raw[i & 1] (V1: slots 8 i + 1, 8 i + 2) precede its first overwrite (V2: slots 8 i + 3, 8 i + 4), and chunk i + 1's tile
+      // (complete by slot 8 i) is first read in V3 (8 i + 5).  Operands are built in the cluster in front of their MFMAs and die
+      // with them: one set of planes (12 registers) instead of two, and position b's no longer wait in LDS.
+      {
+        bf16x8 vs[3];
+        const bool late = wave >= 4;                    // (waves w and w + 4 share SIMD w & 3)
+        // position b's transformed values (two quads) wait in LDS from their transform to their split, two clusters later:
+        // [quad][thread], every thread reads what it wrote (8 registers fewer across the staging clusters, whose global loads
+        // would otherwise spill -- a spill reload waits on vmcnt(0), i.e. on every load in flight)
+        f32x4* bpark = zone + 2 * WHI * WNT;
+        auto park_vb = [&]() {
+          if (!SR3_WINO_PARKB) return;
+          int t_ = tid;
+          asm volatile("" : "+v"(t_));
+          bpark[t_] = vb0; bpark[WNT + t_] = vb1;
+        };
+        auto fetch_vb = [&]() {
+          if (!SR3_WINO_PARKB) return;
+          int t_ = tid;
+          asm volatile("" : "+v"(t_));
+          vb0 = bpark[t_]; vb1 = bpark[WNT + t_];
+        };
+        {
+          f32x4 da[3], db[3];
+          t_load(raw0, 0, 0, da, db);
+          t_finish(da, db, va0, vb0);
+          t_load(raw0, 0, 1, da, db);
+          t_finish(da, db, va1, vb1);
+          sp3(va0, va1, vs[0], vs[1], vs[2]);
+          park_vb();
+        }
+        // Cluster barriers.  Behind a VALU cluster: a bare s_barrier -- the LDS reads issued at the cluster's end for the NEXT VALU
+        // cluster (transform rows, parked values, staging items) stay in flight across the barrier and the MFMA cluster, so their
+        // latency is paid by nobody.  Behind an MFMA cluster: lgkmcnt(0) first (those reads are consumed next anyway), which is
+        // also what completes the staging cluster's LDS writes before any other wave can read them (their first reader is a whole
+        // iteration away).  Not __syncthreads(): its release fence makes the compiler wait for the LDS transfers in flight
+        // (vmcnt(0) right behind their issue) -- their only consumer is the issuing thread itself, behind its own vmcnt wait.
+#if SR3_PP_STRICT
+#define SR3_PP_BARRIER_V() do { SR3_SB(); asm volatile("s_barrier" ::: "memory"); SR3_SB(); } while (0)
+#define SR3_PP_BARRIER_G() do { SR3_SB(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); SR3_SB(); } while (0)
+#define SR3_PP_CHUNK_BARRIER(when_late) do {} while (0)
+#else
+        // relaxed form: ONE workgroup barrier per chunk -- what the raw tiles need (behind every wave's last reads of raw[i & 1],
+        // in front of the staging writes) -- placed one cluster earlier for waves 4-7 (in front of G2) than for waves 0-3 (behind
+        // it): between two barriers every wave runs the same eight clusters, but the pairs of a SIMD leave each barrier in
+        // anti-phase (one into an MFMA cluster, one into a VALU cluster) and run free from there
+#define SR3_PP_BARRIER_V() SR3_SB()
+#define SR3_PP_BARRIER_G() SR3_SB()
+#define SR3_PP_CHUNK_BARRIER(when_late) do { if (late == (when_late)) { SR3_SB(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); SR3_SB(); } } while (0)
+#endif
+        // MFMA hand-off between the two waves of a SIMD (w and w + 4).  Left alone the pair falls into lock step -- both in their
+        // MFMA clusters together (the pipe serialises them: 2 x 12 MFMAs before either goes on), then both in their VALU
+        // clusters -- and a chunk costs 4 (2 G + V).  With the order G(w), G(w + 4), G(w), ... enforced, each wave's VALU cluster
+        // runs beside the other's MFMAs and the other's VALU cluster: 4 (G + V).  Two counters per pair in LDS, one writer each:
+        // clusters issued so far; a wave waits (ds_read + s_sleep) until its partner has issued the cluster in front of its own.
+#if SR3_PP_TOKEN
+        typedef volatile __attribute__((address_space(3))) int* lds_flag_t;       // (explicitly LDS: a generic volatile access is a flat one, vmcnt(0) and all)
+        lds_flag_t tokens = (lds_flag_t)(smem + W_TOK_F);                         // [2][4]: waves 0-3, waves 4-7
+        auto tok_wait = [&]() {
+          const int need = late ? gseq + 1 : gseq;
+          lds_flag_t f = tokens + (late ? 0 : 4) + (wave & 3);
+          while (__builtin_amdgcn_readfirstlane(*f) < need) __builtin_amdgcn_s_sleep(1);
+        };
+        auto tok_done = [&]() {
+          ++gseq;
+          if (lane == 0) tokens[(late ? 4 : 0) + (wave & 3)] = gseq;
+        };
+#else
+        auto tok_wait = [&]() {};
+        auto tok_done = [&]() {};
+#endif
+        constexpr bool PF = (SR3_PP_PREFETCH & 1) != 0, PFS = (SR3_PP_PREFETCH & 2) != 0;     // transform rows / staging reads
+        f32x4 da[3], db[3];                      // row reads of the next transform's first half (PF: in flight across an MFMA cluster)
+        f32x4 rz[WHI], ssq[2];                   // staging: raw items out of the landing zone, GroupNorm pairs -- likewise
+        auto pre_T = [&](const float* rb, int m) { fetch_vb(); t_load(rb, m, 0, da, db); };
+        auto do_T = [&](const float* rb, int m) {              // split b of the current unit ; transform of the next one
+          if (!PF) pre_T(rb, m);
+          f32x4 ta = va0, tb = vb0;
+          t_finish(da, db, ta, tb);
+          t_load(rb, m, 1, da, db);
+          sp3(vb0, vb1, vs[0], vs[1], vs[2]);
+          t_finish(da, db, va1, vb1);
+          va0 = ta; vb0 = tb;
+          park_vb();
+        };
+        auto pre_S = [&](int chunk, int z, int j0, int j1) {
+          zone_read(rz, z, j0, j1);
+          fetch_items(j0, WHI);                  // (the fetch of chunk i + 3 behind items 0, 1 needs the source pixel of all three)
+          load_pairs(chunk, cs_, ssq);
+        };
+        if (SR3_PP_STRICT && late) SR3_PP_BARRIER_G();
+        if (PF) pre_T(raw0, 1);
+        SR3_PP_BARRIER_V();
+        for (int i = 0; i < nck; ++i) {
+          float* rcur = (i & 1) ? raw1 : raw0;
+          const float* rnext = (i & 1) ? raw0 : raw1;
+          const bool more = i + 1 < nck;
+          const bool stage = i + 2 < nck && !(DBG & 32);
+          const int z = i & 1;
+          tok_wait(); SR3_SB(); mfma_split(0, 0, vs); SR3_SB(); tok_done();                                   // G1
+          SR3_PP_BARRIER_G();
+          do_T(rcur, 1);                                          // V1: split b (m0) ; transform m1
+          SR3_SB();
+          if (PFS && stage) {
+            // chunk i + 2's raw items were fetched a whole iteration ago (the prologue for i == 0) and every load issued since --
+            // the U fragments of this chunk -- is consumed by G1 / G2: waiting for all of them here costs nothing
+            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+            SR3_SB();
+            pre_S(c_begin + i + 2, z, 0, 2);
+          }
+          SR3_PP_BARRIER_V();
+          SR3_PP_CHUNK_BARRIER(true);
+          tok_wait(); SR3_SB(); mfma_split(0, 1, vs); SR3_SB(); tok_done();                                   // G2
+          SR3_PP_BARRIER_G();
+          SR3_PP_CHUNK_BARRIER(false);
+          sp3(va0, va1, vs[0], vs[1], vs[2]);                     // V2: split a (m1) ; stage items 0, 1 ; fetch chunk i + 3
+          SR3_SB();
+          if (stage) {
+            if (!PFS) {
+              __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see above
+              SR3_SB();
+              pre_S(c_begin + i + 2, z, 0, 2);
+            }
+            store_raw(rcur, c_begin + i + 2, rz, cs_, 0, 2, ssq);
+            SR3_SB();
+            if (i + 3 < nck) dma_raw(c_begin + i + 3, z ^ 1);
+          }
+          SR3_SB();
+          if (PF) { if (more) pre_T(rnext, 0); else fetch_vb(); }
+          SR3_PP_BARRIER_V();
+          tok_wait(); SR3_SB(); mfma_split(1, 0, vs); SR3_SB(); tok_done();                                   // G3
+          if (more) load_us(c_begin + i + 1, 0);
+          SR3_PP_BARRIER_G();
+          if (more) do_T(rnext, 0);                               // V3: split b (m1) ; transform m0 of chunk i + 1
+          else { if (!PF) fetch_vb(); sp3(vb0, vb1, vs[0], vs[1], vs[2]); }
+          SR3_SB();
+          if (PFS && stage) pre_S(c_begin + i + 2, z, 2, 3);
+          SR3_PP_BARRIER_V();
+          tok_wait(); SR3_SB(); mfma_split(1, 1, vs); SR3_SB(); tok_done();                                   // G4
+          if (more) load_us(c_begin + i + 1, 1);
+          SR3_PP_BARRIER_G();
+          if (more) sp3(va0, va1, vs[0], vs[1], vs[2]);           // V4: split a (m0 of chunk i + 1) ; stage item 2
+          SR3_SB();
+          if (stage) {
+            if (!PFS) pre_S(c_begin + i + 2, z, 2, 3);
+            store_raw(rcur, c_begin + i + 2, rz, cs_, 2, 3, ssq);
+          }
+          SR3_SB();
+          if (PF && more) pre_T(rnext, 1);
+          SR3_PP_BARRIER_V();
+        }
+        if (SR3_PP_STRICT && !late) SR3_PP_BARRIER_G();
+#undef SR3_PP_BARRIER_V
+#undef SR3_PP_BARRIER_G
+#undef SR3_PP_CHUNK_BARRIER
+      }
+#else
       {
         f32x4 da[3], db[3];
         t_load(raw0, 0, 0, da, db);
@@ -785,6 +1027,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           sp3(va0, va1, vsa[0], vsa[1], vsa[2]);
         }
       }
+#endif
     } else {
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       {

@@ -135,9 +135,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
       wok[S][j] = ok;
       const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
       if constexpr (WPRE) {
-        const bf16x4* q = reinterpret_cast<const bf16x4*>(p.w_split) + (size_t)(off >> 2) * 3;
+        const size_t wq = (size_t)p.Cout * TAPS * (Cin >> 2);               // quads per plane
+        const bf16x4* q = reinterpret_cast<const bf16x4*>(p.w_split) + (size_t)(off >> 2);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rws[S][j][pl] = q[pl];
+        for (int pl = 0; pl < 3; ++pl) rws[S][j][pl] = q[(size_t)pl * wq];
       } else {
         rw[S][j] = *reinterpret_cast<const f32x4*>(p.w + off);
       }
@@ -398,15 +399,17 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
 }
 
 // ---- pre-split weights of the SPLIT instantiations (ConvParams::w_split) --------------------------------------------------------
-// out[quad q][plane 3][4] bf16 with q = (OHWI element index) / 4: the three bf16 terms of the four weights of a channel quad next
-// to each other (24 bytes), so the loader's three 8-byte loads of a quad are one contiguous 24-byte run
+// out[plane 3][quad q][4] bf16 with q = (OHWI element index) / 4: three planes in the weights' own order, so each of the loader's
+// three 8-byte loads of a quad is coalesced like the fp32 load it replaces (64 contiguous bytes per 32-channel row; the first
+// layout, [quad][plane][4] = one 24-byte run per thread, made every load instruction touch 3x the lines it used and was SLOWER
+// than splitting in the kernel: 1.52 vs 1.43 ms over the 33 launches)
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, long nquads, __bf16* __restrict__ out) {
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(w + q * 4);
     bf16x4 h, m, l;
     split3(v, h, m, l);
-    bf16x4* o = reinterpret_cast<bf16x4*>(out) + q * 3;
-    o[0] = h; o[1] = m; o[2] = l;
+    bf16x4* o = reinterpret_cast<bf16x4*>(out) + q;
+    o[0] = h; o[nquads] = m; o[2 * nquads] = l;
   }
 }
 size_t igemm_wsplit_floats(size_t numel) { return ((numel / 4) * 6 + 3) & ~(size_t)3; }     // 24 bytes per quad, rounded to 16 bytes

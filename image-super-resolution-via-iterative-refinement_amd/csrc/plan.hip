@@ -623,7 +623,7 @@ void layout_derived(sr3_plan* P) {
   // (3x3 stride 2; Cout <= 64 stays on the fp32 MFMA: Builder::conv)
   P->wsplits.clear();
   P->wsplit_of.clear();
-  if (P->gemm_split) {
+  if (P->gemm_split && P->gemm_wpre) {
     auto regw = [&](size_t w, size_t numel) {
       if (numel & 3) return;
       P->wsplits.push_back({w, numel, dcur});
@@ -1009,6 +1009,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
+  else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino4")) slot = &plan->wino4;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
@@ -1019,7 +1020,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
-  if ((slot == &plan->wino_split || slot == &plan->gemm_split) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
+  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }

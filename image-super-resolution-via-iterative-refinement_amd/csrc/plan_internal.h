@@ -110,6 +110,9 @@ struct sr3_plan {
                              // one-image tile of the inference plan.  0: the exact-fp32 MFMA instantiation everywhere
   int gemm_tile = 0;         // A/B knob: force this im2col tile (1-4) on every conv of that kernel; 0 = conv_pick's choice
   int gemm_split = 1;        // the im2col kernel (1x1 and stride-2 convs) on its 3 x bf16 split instantiations (conv_igemm.hip)
+  int gemm_wpre = 0;         // 1: ... reading their weights pre-split (three bf16 planes in the derived buffer). Measured SLOWER in the
+                             // forward (1.59 vs 1.50 ms over the 33 launches, profiles/r05c_*: 1.5x the weight bytes, three loads per
+                             // quad) -- off by default, kept as tiles 18-21 at the ABI and as this A/B knob
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;

@@ -173,14 +173,26 @@ def test_plan_launch_list_no_gpu():
         assert not o['fused_res_conv_cin']
         if o['tile_cfg'] == 11 and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
             assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
+    # the im2col SPLIT tiles split their weights while staging them by default (tiles 14-17); plan option gemm_wpre = 1 (measured
+    # slower, kept as an A/B knob): they read them pre-split from the derived buffer (tiles 18-21), three bf16 planes = 6 bytes per
+    # weight of the res_convs, attention projections and Downsample convs with Cout > 64
+    assert all(not 18 <= o['tile_cfg'] <= 21 for o in wconvs) and any(14 <= o['tile_cfg'] <= 17 for o in wconvs)
+    nbytes_nopre = int(p.lib.sr3_plan_derived_bytes(p.handle))
+    p.set_option('gemm_wpre', 1)
+    pre = [o for o in p.op_list(16) if o['kind'] == 50]
     nbytes_both = int(p.lib.sr3_plan_derived_bytes(p.handle))
-    # ... of which the pre-split 1x1 / stride-2 weights of the im2col SPLIT tiles (plan option gemm_split): three bf16 planes =
-    # 6 bytes per weight of the res_convs, attention projections and Downsample convs with Cout > 64
+    nbytes_wsplit = nbytes_both - nbytes_nopre
+    n_w = sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in pre if 18 <= o['tile_cfg'] <= 21)
+    assert n_w > 0 and nbytes_wsplit == 6 * n_w
+    assert all((18 <= a['tile_cfg'] <= 21) == (14 <= b['tile_cfg'] <= 17) and a['tile_cfg'] in (b['tile_cfg'], b['tile_cfg'] + 4)
+               for a, b in zip(pre, wconvs))
     p.set_option('gemm_split', 0)
-    nbytes_wsplit = nbytes_both - int(p.lib.sr3_plan_derived_bytes(p.handle))
+    assert int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_nopre      # nothing pre-split without the split tiles
     p.set_option('gemm_split', 1)
-    n_w = sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in wconvs if 18 <= o['tile_cfg'] <= 21)
-    assert nbytes_wsplit == 6 * n_w and int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_both
+    assert int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_both
+    p.set_option('gemm_wpre', 0)
+    assert p.op_list(16) == wops
+    nbytes_both, nbytes_wsplit = nbytes_nopre, 0
     p.set_option('wino_split', 0)                         # the exact-fp32 MFMA instantiation everywhere: same list, tile 11
     eops = p.op_list(16)
     assert len(eops) == len(wops)
@@ -207,10 +219,10 @@ def test_plan_launch_list_no_gpu():
         halo = 5 <= o['tile_cfg'] <= 10
         assert halo == (o['ksize'] == 3 and o['stride'] == 1), o
         # 1x1 / stride-2 convs: the im2col kernel's 64x64 tile on its 3 x bf16 split instantiation (plan option gemm_split,
-        # default 1; reported as tile 20 = the split form of tile 3 with pre-split weights from the derived buffer); the 9-tap
+        # default 1; reported as tile 16 = the split form of tile 3; 20 with pre-split weights under gemm_wpre = 1); the 9-tap
         # Downsample with Cout <= 64 stays on the fp32 MFMA
         if not halo:
-            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 20), o
+            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 16), o
         if o['fused_res_conv_cin']:
             assert halo and not o['upsample']
     # 18 ResnetBlocks change their channel count: where block2's conv runs unsplit (the 128x128 and 64x64 levels) their
@@ -235,8 +247,8 @@ def test_plan_launch_list_no_gpu():
     p.set_option('gemm_split', 0)
     for a, b in zip(ops, p.op_list(16)):
         assert a['kind'] == b['kind'] and a['flops'] == b['flops']
-        if a['kind'] == 50 and 18 <= a['tile_cfg'] <= 21:
-            assert b['tile_cfg'] == a['tile_cfg'] - 17 == 3 and a['ksplit'] == b['ksplit'], (a, b)
+        if a['kind'] == 50 and 14 <= a['tile_cfg'] <= 17:
+            assert b['tile_cfg'] == a['tile_cfg'] - 13 == 3 and a['ksplit'] == b['ksplit'], (a, b)
         else:
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('gemm_split', 1)

@@ -42,8 +42,10 @@ __device__ __forceinline__ void filler(float (&v)[8], f32x2 (&w)[4], f32x4& ld, 
   else if (CLS == C_MOV64) asm volatile("v_mov_b64 %0, %1" : "=v"(w[i & 3]) : "v"(w[(i + 1) & 3]));
 }
 
-// MODE 0 interleaved, 1 clustered, 2 anti-phase (waves >= 4 run the filler cluster first)
-template <int CLS, int N, int MODE>
+// MODE 0 interleaved, 1 clustered, 2 anti-phase (waves >= 4 run the filler cluster first), 3 ping-pong: clustered with an
+// s_barrier behind every cluster, waves >= 4 one barrier ahead -- the workgroup barrier is the metronome that keeps one wave of
+// every SIMD in its MFMA cluster while the other is in its filler cluster (MT MFMAs per cluster)
+template <int CLS, int N, int MODE, int MT = 16>
 __global__ __launch_bounds__(512, 1) void k(float* out, int iters) {
   __shared__ f32x4 buf[2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,8 +67,16 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters) {
 #pragma unroll
     for (int i = 0; i < 16 * N; ++i) filler<CLS>(v, w, ld, addr, i);
   }
+  if (MODE == 3 && wave >= 4) __builtin_amdgcn_s_barrier();
   for (int it = 0; it < iters; ++it) {
-    if (MODE == 0) {
+    if (MODE == 3) {
+#pragma unroll
+      for (int q = 0; q < MT; ++q) MFMA(acc[q & 3]);
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < MT * N; ++i) filler<CLS>(v, w, ld, addr, i);
+      __builtin_amdgcn_s_barrier();
+    } else if (MODE == 0) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         MFMA(acc[q & 3]);
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters) {
     }
     if (CLS == C_LDSR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  if (MODE == 3 && wave < 4) __builtin_amdgcn_s_barrier();
   float s = ld.x;
   for (int i = 0; i < 4; ++i)
     for (int r = 0; r < 16; ++r) s += acc[i][r];
@@ -89,15 +100,15 @@ __global__ __launch_bounds__(512, 1) void k(float* out, int iters) {
   out[blockIdx.x * 512 + tid] = s;
 }
 
-template <int CLS, int N, int MODE>
+template <int CLS, int N, int MODE, int MT = 16>
 float run(float* out, int threads) {
-  const int iters = 2048, blocks = 256;
+  const int iters = 2048 * 16 / MT, blocks = 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<CLS, N, MODE>), dim3(blocks), dim3(threads), 0, 0, out, 16);
+  hipLaunchKernelGGL((k<CLS, N, MODE, MT>), dim3(blocks), dim3(threads), 0, 0, out, 16);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k<CLS, N, MODE>), dim3(blocks), dim3(threads), 0, 0, out, iters);
+  hipLaunchKernelGGL((k<CLS, N, MODE, MT>), dim3(blocks), dim3(threads), 0, 0, out, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
@@ -122,6 +133,10 @@ void row(float* out) {
          cyc(run<CLS, 4, 1>(out, 512)), cyc(run<CLS, 5, 1>(out, 512)), cyc(run<CLS, 6, 1>(out, 512)), cyc(run<CLS, 8, 1>(out, 512)));
   printf("%-18s 2 waves/SIMD anti-phase  N=2 %6.1f  N=4 %6.1f  N=5 %6.1f  N=6 %6.1f  N=8 %6.1f\n", "", cyc(run<CLS, 2, 2>(out, 512)),
          cyc(run<CLS, 4, 2>(out, 512)), cyc(run<CLS, 5, 2>(out, 512)), cyc(run<CLS, 6, 2>(out, 512)), cyc(run<CLS, 8, 2>(out, 512)));
+  printf("%-18s 2 waves/SIMD ping-pong16 N=2 %6.1f  N=4 %6.1f  N=5 %6.1f  N=6 %6.1f  N=8 %6.1f   (s_barrier behind every 16-MFMA / 16N-filler cluster)\n", "",
+         cyc(run<CLS, 2, 3>(out, 512)), cyc(run<CLS, 4, 3>(out, 512)), cyc(run<CLS, 5, 3>(out, 512)), cyc(run<CLS, 6, 3>(out, 512)), cyc(run<CLS, 8, 3>(out, 512)));
+  printf("%-18s 2 waves/SIMD ping-pong12 N=2 %6.1f  N=4 %6.1f  N=5 %6.1f  N=6 %6.1f  N=8 %6.1f   (12-MFMA clusters: the Winograd loop's groups)\n", "",
+         cyc(run<CLS, 2, 3, 12>(out, 512)), cyc(run<CLS, 4, 3, 12>(out, 512)), cyc(run<CLS, 5, 3, 12>(out, 512)), cyc(run<CLS, 6, 3, 12>(out, 512)), cyc(run<CLS, 8, 3, 12>(out, 512)));
 }
 
 int main() {
