@@ -1014,12 +1014,13 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         }
         SR3_SB();
         fetch_b();
+        if ((PRE & 2) && more) t_load(rnext, 0, 1, da, db);
         SR3_SB();
         mfma_split(1, 1, vsb);
         SR3_SB();
         if (more) {
           load_us(c_begin + i + 1, 1);
-          t_load(rnext, 0, 1, da, db);
+          if (!(PRE & 2)) t_load(rnext, 0, 1, da, db);
           t_finish(da, db, va1, vb1);
           SR3_SB();
           park_b();
@@ -1324,13 +1325,14 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
   if (p.wino_split == 2 && g.NB == 1 && p.drop_thresh == 0) return conv3x3_wino4_forward(p, g, ufrag, st);
-  if (p.wino_split && g.NB != 1) {
-    set_error("conv: the split-bf16 Winograd kernel covers the one-image tile only");
+  if (p.wino_split && g.NB != 1 && p.drop_thresh != 0) {
+    set_error("conv: the split-bf16 four-image Winograd tile has no dropout form");
     return SR3_E_UNSUPPORTED;
   }
   switch (dbg) {
     case 0:
       if (p.wino_split && p.drop_thresh != 0) { SR3_WINO_LAUNCH4(0, true, false, true) }
+      else if (p.wino_split && g.NB != 1) { SR3_WINO_LAUNCH4(0, false, true, true) }
       else if (p.wino_split) { SR3_WINO_LAUNCH4(0, false, false, true) }
       else if (p.drop_thresh != 0) { SR3_WINO_LAUNCH2(0, true) } else { SR3_WINO_LAUNCH2(0, false) }
       break;

@@ -395,8 +395,8 @@ struct Builder {
       // plan option wino_split: the 3 x bf16 split instantiation where it exists (the one-image tile; training plan and
       // train-mode dropout included); its filters sit behind the conv's fp32 ones
       WinoGeom wg;
-      if (P->wino_split && wino_geometry(c, &wg) && wg.NB == 1) {
-        c.wino_split = (P->wino4 && !o.has_drop) ? 2 : 1;
+      if (P->wino_split && wino_geometry(c, &wg) && (wg.NB == 1 || (P->wino_split8 && !o.has_drop))) {
+        c.wino_split = (P->wino4 && !o.has_drop && wg.NB == 1) ? 2 : 1;
         o.wino_off += wino_weight_floats(Cout, C0 + C1);
       }
     }
@@ -1008,6 +1008,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "split_bf16")) slot = &plan->split_bf16;
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
+  else if (!strcmp(key, "wino_split8")) slot = &plan->wino_split8;
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;

@@ -168,10 +168,10 @@ def test_plan_launch_list_no_gpu():
     for o in wconvs:
         assert (o['tile_cfg'] in (11, 12)) == (o['ksize'] == 3 and o['stride'] == 1), o
         # default plan option wino_split = 1: the one-image tile (maps >= 16x16) on the kernel's 3 x bf16 split instantiation
-        # (reported as tile 12), the four-image tile of the 8x8 maps on the fp32-MFMA one
-        assert (o['tile_cfg'] == 12) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
+        # (reported as tile 12), and since round 5 (plan option wino_split8, default 1) the four-image tile of the 8x8 maps too
+        assert (o['tile_cfg'] == 12) == (o['ksize'] == 3 and o['stride'] == 1), o
         assert not o['fused_res_conv_cin']
-        if o['tile_cfg'] == 11 and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
+        if o['tile_cfg'] in (11, 12) and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
             assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
     # the im2col SPLIT tiles split their weights while staging them by default (tiles 14-17); plan option gemm_wpre = 1 (measured
     # slower, kept as an A/B knob): they read them pre-split from the derived buffer (tiles 18-21), three bf16 planes = 6 bytes per

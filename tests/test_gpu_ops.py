@@ -284,7 +284,7 @@ def test_winograd_conv_error_is_fp32_class(case, ksplit):
     assert rms_w <= 3.0 * rms_d + 1e-8 * ref.abs().max().item(), (rms_w, rms_d)
 
 
-SPLIT_GATE_CASES = [c for c in WINO_CASES if c[4] >= 16]          # (the four-image 8x8 tile has no split instantiation)
+SPLIT_GATE_CASES = list(WINO_CASES)          # (round 5: the four-image 8x8 tile has its split instantiation too -- tile 12 only)
 
 
 @pytest.mark.parametrize('tile', [12, 13], ids=['8wave', '4wave'])
@@ -295,13 +295,15 @@ def test_winograd_split_error_not_above_fp32_winograd(case, ksplit, tile):
     as h + m + l, six bf16 MFMA products per term, fp32 accumulation): on every layer shape of the BASELINE networks its error
     against float64 must not exceed the exact-fp32 Winograd kernel's (tile 11) on the same data -- rms within 5 %, max within
     25 % (the max of ~1e6 samples is a noisy statistic) -- and it must meet the same stated tolerance."""
+    if case[4] < 16 and tile == 13:
+        pytest.skip('the four-wave kernel covers the one-image tile only')
     src0, src1, w, kw = _make_case(case, seed=7)
     ref = G.conv_ref(src0, src1, w, **kw)
     try:
         got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
         base, _ = G.conv_call(src0, src1, w, tile_cfg=11, ksplit=ksplit, **kw)
     except L.Sr3Error as e:
-        if 'empty split' in str(e):
+        if 'empty split' in str(e) or 'split-K only' in str(e) or 'per K split' in str(e):
             pytest.skip(str(e))
         raise
     assert not torch.isnan(got).any()
