@@ -43,7 +43,7 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 # sr3_unet_forward_profile op kinds (plan.hip): Winograd fp32 one-image / four-image tile, SPLIT one-image / four-image tile,
 # four-wave SPLIT kernel; im2col SPLIT tiles 14-17
 WINO_KINDS = (455, 465, 555, 565, 575)
@@ -243,7 +243,9 @@ def oracle_train_baseline(cfg_name, sd, batch, device, cores, steps=3):
     t_step = sum(times) / len(times)
     return dict(value=batch / t_step, unit='images/s', s_per_step=t_step, batch=batch, cores=cores,
                 sample='%d Adam steps at batch %d after 1 warm-up (autograd over the oracle ops on %s; the dropout of the '
-                       'training config is left out of this baseline)' % (len(times), batch, device))
+                       'training config is left out of this baseline: it flatters the baseline -- the reference itself, dropout '
+                       'included, takes 1.76x as long per step on the same cores, profiles/r04_ref_vs_port_cpu.json)'
+                       % (len(times), batch, device))
 
 
 def reference_cpu_baseline(ref, cfg_name, netG, par, cores, budget_s, train_batch):
@@ -482,29 +484,30 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
     Adam, dropout as configured), data parallel with bucketed RCCL all-reduce of the gradients."""
     import numpy as np
     import torch
-    import model as Model
+    if not STUB:
+        import model as Model
     c = CONFIGS[cfg_name]
     opt = config_opt(cfg_name, phase='train')
     torch.manual_seed(1000 + rank)              # per-rank streams (z, dropout seed, data); create_model broadcasts rank 0's weights
     np.random.seed(1234 + rank)
-    m = Model.create_model(opt)
+    m = _StubModel(cfg_name, dist, dev) if STUB else Model.create_model(opt)
     S = c['size']
     g = torch.Generator().manual_seed(77 + rank)
     data = {'HR': torch.rand(batch, 3, S, S, generator=g) * 2 - 1, 'SR': torch.rand(batch, 3, S, S, generator=g) * 2 - 1}
     m.feed_data(data)
     for _ in range(warmup):
         m.optimize_parameters()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         m.optimize_parameters()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     dt = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -518,14 +521,29 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'optimizer': 'Adam lr %g' % c['lr'],
             'parallelism': 'dp%d, tail-first 32 MB gradient buckets all-reduced (RCCL) as the backward produces them' % world,
             'tflops_at_3x_forward': fl / (ms * 1e-3) / 1e12,
-            'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix']}
+            'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix'],
+            **({'stub': True, 'gradient_buckets_walked': m.buckets_walked,
+                'gradient_buckets_per_step': len(m.red.buckets) if m.red else 0} if STUB else {})}
+
+
+def headline_dtype(plan, batch):
+    """`dtype` of the line from the plan's EFFECTIVE launch list (an A/B run's --plan-opt included), not from the flags: any
+    conv on a 3 x bf16 split instantiation (Winograd 12 / 13, im2col 14-21, the opt-in halo tiles 7 / 8 / 10) -> the split
+    label, none -> plain f32."""
+    split_tiles = {7, 8, 10, 12, 13} | set(range(14, 22))
+    return 'f32 via 3xbf16 split MFMA' if any(o['tile_cfg'] in split_tiles for o in plan.op_list(batch)) else 'f32'
 
 
 def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=False, plan_opts=None):
     """define_G of a BASELINE.json network (random init, seed 0), its reverse-step hipGraph captured at batch B."""
     import torch
-    import model.networks as networks
     cfg = CONFIGS[cfg_name]
+    if STUB:
+        S = cfg['size']
+        st = {'img': torch.randn(B, 3, S, S), 'step': torch.zeros(1, dtype=torch.int32), 'cond': None}
+        st['graph'] = _StubGraph(st)
+        return _StubNet(cfg_name), st
+    import model.networks as networks
     torch.manual_seed(0)
     opt = config_opt(cfg_name, T)
     netG = networks.define_G(opt).to(dev)
@@ -552,6 +570,76 @@ def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=F
     return netG, st
 
 
+STUB = bool(os.environ.get('SR3_BENCH_STUB'))      # CPU / gloo plumbing test (tests/test_dist_gloo.py): the engine is replaced by
+                                                   # stand-ins, everything else -- launcher, rank checks, barriers, MAX over ranks,
+                                                   # the record, the training leg's bucket walk -- is the code the GPU run takes
+
+
+def dev_sync(dev):
+    import torch
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
+
+
+class _StubGraph(object):
+    def __init__(self, st):
+        self.st = st
+
+    def replay(self):
+        self.st['img'].mul_(0.999)
+        self.st['step'].sub_(1)
+
+
+class _StubPlan(object):
+    """Host-only facts of the real plan (parameter table, FLOPs, launch list) -- sr3_plan_create does no device work."""
+    def __init__(self, cfg_name):
+        from sr3_hip import engine as E
+        c = CONFIGS[cfg_name]
+        u = c['unet']
+        self.p = E.Plan(c['which'], u['in_channel'], u['out_channel'], u['inner_channel'], u.get('norm_groups', 32),
+                        u['channel_multiplier'], u['attn_res'], u['res_blocks'], c['size'])
+        self.table = self.p.table
+
+    def forward_flops(self, b):
+        return self.p.forward_flops(b)
+
+    def op_list(self, b):
+        return self.p.op_list(b)
+
+
+class _StubNet(object):
+    def __init__(self, cfg_name):
+        self.denoise_fn = type('U', (), {})()
+        self.denoise_fn.plan = _StubPlan(cfg_name)
+        self._loop_cache = {}
+
+
+class _StubModel(object):
+    """optimize_parameters of the stub: a gradient arena of the real size walked by the real GradReducer (tail-first 32 MB
+    buckets, gloo all-reduce), i.e. what model/model.py does behind sr3_train_step."""
+    def __init__(self, cfg_name, dist, dev):
+        import torch
+        from sr3_hip import dist as D
+        self.netG = _StubNet(cfg_name)
+        n = sum(e['numel'] for e in self.netG.denoise_fn.plan.table)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.red = D.GradReducer(n, dev, dist) if dist else None
+        self.buckets_walked = 0
+        self.loss = torch.zeros(1)
+
+    def feed_data(self, data):
+        self.data = data
+
+    def optimize_parameters(self):
+        self.grads.fill_(1.0)
+        if self.red:
+            self.red.reduce(self.grads, extra=[self.loss])
+            self.buckets_walked += len(self.red.buckets)
+
+    def get_current_log(self):
+        return {'l_pix': float(self.grads[0])}
+
+
 def time_replays(st, steps, warmup, T, dist, dev):
     """W untimed + exactly K timed graph replays (chains of T steps), barrier + synchronize on both sides, MAX over ranks."""
     import torch
@@ -561,10 +649,10 @@ def time_replays(st, steps, warmup, T, dist, dev):
         graph.replay()
     st['step'].fill_(T - 1)
     st['img'].normal_()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     t0 = time.perf_counter()
     done = 0
     while done < steps:                                   # exactly K steps, chains of T
@@ -575,10 +663,10 @@ def time_replays(st, steps, warmup, T, dist, dev):
         if done < steps:
             st['step'].fill_(T - 1)
             st['img'].normal_()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     if dist:
         dist.barrier()
-    torch.cuda.synchronize(dev)
+    dev_sync(dev)
     elapsed = time.perf_counter() - t0
     if dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -628,7 +716,7 @@ def other_config_leg(cfg_name, dev, steps=50, warmup=3, T=2000):
 def self_launch(n):
     """`python bench.py --gpus N` outside a launcher: start the N ranks (one process per GPU, RCCL over 127.0.0.1)."""
     import torch
-    have = torch.cuda.device_count()
+    have = n if STUB else torch.cuda.device_count()
     if have < n:
         sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report n_gpus=%d\n' % (n, have, n))
         return 2
@@ -688,7 +776,7 @@ def main():
     sys.path.insert(0, PKG)
     sys.path.insert(0, ROOT)
     import torch
-    if torch.cuda.device_count() <= local:
+    if not STUB and torch.cuda.device_count() <= local:
         sys.stderr.write('bench.py: rank %d needs cuda:%d but %d device(s) are visible\n' % (rank, local, torch.cuda.device_count()))
         sys.exit(2)
     # Joining the job is the drop-in's own code path (sr3_hip.dist.bootstrap: cuda:LOCAL_RANK, RCCL group bound to it, per-rank
@@ -706,8 +794,11 @@ def main():
         sys.stderr.write('bench.py: bootstrap gave rank %d/%d local %d, the launcher said %d/%d local %d\n'
                          % (b_rank, b_world, b_local, rank, world, local))
         sys.exit(2)
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if STUB:
+        dev = torch.device('cpu')
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     dist = None
     if D.dp_active():
         import torch.distributed as dist
@@ -733,7 +824,8 @@ def main():
         # fp32 tensors and fp32 accumulation everywhere; the Winograd contractions of maps >= 16x16 (the dominant kernel) evaluate
         # each fp32 product as six bf16 MFMA products of 3-way split operands (plan option wino_split, default on, gated in tests/);
         # `exact_fp32` below is the same step with that option off
-        'dtype': 'f32 via 3xbf16 split MFMA' if (a.split_bf16 or not a.exact_fp32) else 'f32', 'data': 'synthetic',
+        'dtype': headline_dtype(netG.denoise_fn.plan, B),
+        'data': 'synthetic' if not STUB else 'STUB: CPU plumbing test, no engine -- the numbers mean nothing',
         'config': {'workload': '%s UNet (reference %s; BASELINE.json configs[%d]), batch %d per GPU, 2000-step p_sample_loop via '
                                'hipGraph replay; step = one reverse step of the batch; images/s = n_gpus*batch/(2000*t_step)'
                                % (cfg['title'], cfg['ref_json'], cfg['baseline_cfg'], B),
@@ -763,7 +855,7 @@ def main():
     timer.start()
 
     par = None
-    if rank == 0:
+    if rank == 0 and not STUB:
         try:
             par = capture_parity_inputs(netG, st, cfg, T)
         except Exception as e:
@@ -821,6 +913,12 @@ def main():
             except Exception as e:
                 rec['other_configs'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+        # BASELINE.json configs[4] as a TRAINING workload (DDPM-128, batch 32 / GPU, dropout 0.2): a bounded leg of 5 steps
+        try:
+            rec['other_configs']['ddpm_128_train'] = train_leg('ddpm_128', None, 1, 0, dev, CONFIGS['ddpm_128']['train_batch'], 5, 2)
+        except Exception as e:
+            rec['other_configs']['ddpm_128_train'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
     timer.cancel()
     emit()
     if dist:

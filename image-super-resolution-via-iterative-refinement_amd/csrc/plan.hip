@@ -828,6 +828,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       memset(&g, 0, sizeof(g));
       g.C0 = o.C; g.B = B; g.Hs = x0.H << r.ups; g.Ws = x0.W << r.ups; g.stride = 1; g.ksize = r.ksize;
       g.Ho = g.Hs; g.Wo = g.Ws; g.Cout = c.C0 + c.C1;
+      g.igemm_split = (P->gemm_split && !(g.ksize == 3 && g.Cout <= 64)) ? 1 : 0;      // (what dgrad_conv launches with: train_plan.hip)
       max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
       {   // the data gradient of a 3x3 conv runs on the Winograd kernel where it fits: its slabs and transformed filters
         WinoGeom wg;
@@ -937,6 +938,16 @@ extern "C" {
 
 int sr3_version(void) { return SR3_ABI_VERSION; }
 const char* sr3_last_error(void) { return sr3::last_error(); }
+int sr3_selftest_split3(int* scratch_dev, int* mismatches, void* stream) {
+  if (!scratch_dev || !mismatches) { sr3::set_error("null argument"); return SR3_E_BADARG; }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = sr3::split3_selftest(scratch_dev, st);
+  if (rc) return rc;
+  SR3_HIP(hipMemcpyAsync(mismatches, scratch_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  SR3_HIP(hipStreamSynchronize(st));
+  if (*mismatches != 0) { sr3::set_error("split3 self-test: %d of 2097152 elements do not satisfy x == h + m + l exactly (compiler / ISA change?)", *mismatches); return SR3_E_UNSUPPORTED; }
+  return SR3_OK;
+}
 
 int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out) {
   if (!desc || !out) { set_error("null argument"); return SR3_E_BADARG; }

@@ -146,6 +146,52 @@ int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Self-test of split3_pair (sr3_common.h): every split kernel rests on x == h + m + l holding EXACTLY, and the shipped form of
+// the helper depends on two things no compiler promises -- the bf16 selector pairs staying in registers (folded into the inline
+// constant -1.0 they read as (0, -1) for both elements) and v_dot2c_f32_bf16 producing the exactly representable residual.  One
+// workgroup splits a set of fp32 patterns (random bits over the normal range, powers of two, values one ulp either side of a bf16
+// rounding boundary, zeros, a value with 24 set mantissa bits) and counts the elements whose three terms do not add back to the
+// input bit for bit, or whose terms are not bf16-exact halves of the residual chain.  Run by __graft_entry__.smoke() and a GPU test.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split3_selftest(int n, unsigned seed, int* __restrict__ bad) {
+  int nbad = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned r = hash32((unsigned)(2 * i + e) * 0x9E3779B9u + seed);
+      unsigned bits;
+      switch (i & 7) {
+        case 0: bits = (r & 0x807fffffu) | (((r >> 23) % 200u + 27u) << 23); break;          // random mantissa, exponent 27..226
+        case 1: bits = ((r >> 23) % 200u + 27u) << 23; break;                                 // powers of two
+        case 2: bits = (r & 0xffff0000u & 0x807fffffu) | (100u << 23) | 0x00007fffu; break;   // just below a bf16 tie
+        case 3: bits = (r & 0xffff0000u & 0x807fffffu) | (140u << 23) | 0x00008001u; break;   // just above a bf16 tie
+        case 4: bits = (r & 0x80000000u) | (127u << 23) | 0x007fffffu; break;                 // 24 set significand bits
+        case 5: bits = r & 0x80000000u; break;                                                // +-0
+        case 6: bits = (r & 0x807fffffu) | (127u << 23); break;                               // [1, 2)
+        default: bits = (r & 0xffff8000u & 0x807fffffu) | (90u << 23) | 0x00008000u; break;   // exact ties
+      }
+      x[e] = __builtin_bit_cast(float, bits);
+    }
+    bf16x2 h, m, l;
+    split3_pair(x[0], x[1], h, m, l);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float back = ((float)h[e] + (float)m[e]) + (float)l[e];          // every partial sum is exactly representable
+      if (__builtin_bit_cast(unsigned, back) != __builtin_bit_cast(unsigned, x[e]) && !(back == 0.f && x[e] == 0.f)) ++nbad;
+    }
+  }
+  if (nbad) atomicAdd(bad, nbad);
+}
+
+int split3_selftest(int* bad_dev, hipStream_t st) {
+  SR3_HIP(hipMemsetAsync(bad_dev, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_split3_selftest, dim3(64), dim3(256), 0, st, 1 << 20, 0x5eedu, bad_dev);
+  SR3_LAUNCH_CHECK("k_split3_selftest");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Input conv (unet.py:193-194): 3x3 pad 1 over the virtual concat of two NCHW tensors
 // (`torch.cat([condition_x, x], dim=1)`, diffusion.py:157) -> NHWC.  K = 9*(Ca+Cb) is tiny (54),
 // so this is a direct fp32 FMA kernel bound by the NHWC write: lanes = 64 consecutive pixels

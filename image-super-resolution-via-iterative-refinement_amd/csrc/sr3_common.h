@@ -264,6 +264,8 @@ struct StepTables { const float* a; const float* b; const float* c1; const float
 int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
                     const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st, bool clip = true);
 int step_decrement(int* step_dev, hipStream_t st);
+// split3_pair self-test (small_kernels.hip): *bad_dev = number of elements whose three bf16 terms do not add back exactly
+int split3_selftest(int* bad_dev, hipStream_t st);
 // q_sample (sr3: per-sample gamma; ddpm: a[t], s[t]) -> x_noisy ; l1 loss sum
 int q_sample(const float* x0, const float* z, const float* ca, const float* cb, int B, int per_image,
              float* out, hipStream_t st);

@@ -54,7 +54,9 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
     c.wino_u = wu;
     return conv_forward(c, 11, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
   }
-  c.igemm_split = X.P->gemm_split;             // 1x1 / 8x8 data gradients on the im2col kernel: its 3 x bf16 split instantiation, as the forward
+  // 1x1 / 8x8 data gradients on the im2col kernel: its 3 x bf16 split instantiation, with the forward Builder's exclusion (9-tap
+  // layers producing <= 64 channels stay on the fp32 MFMA: plan.hip, Builder::conv) -- build_train sizes the scratch with the same rule
+  c.igemm_split = (X.P->gemm_split && !(ksize == 3 && c.Cout <= 64)) ? 1 : 0;
   return conv_forward(c, 0, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
 }
 

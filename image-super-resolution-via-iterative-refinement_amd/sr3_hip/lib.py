@@ -52,6 +52,7 @@ SIGNATURES = {
     'sr3_resize_u8': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     'sr3_images_u8_to_f32': (_I, [_P, _I, _I, _I, _I, _P, _F, _F, _P, _P]),
     'sr3_version': (_I, []),
+    'sr3_selftest_split3': (_I, [_P, C.POINTER(C.c_int), _P]),
     'sr3_last_error': (C.c_char_p, []),
     'sr3_plan_create': (_I, [C.POINTER(UnetDesc), C.POINTER(_P)]),
     'sr3_plan_destroy': (None, [_P]),

@@ -65,6 +65,10 @@ typedef struct sr3_plan sr3_plan;
 
 int sr3_version(void);
 const char* sr3_last_error(void);
+/* Device self-test of the 3 x bf16 operand split every SPLIT kernel rests on (x == h + m + l exactly, 2^21 fp32 patterns):
+ * scratch_dev = one int of device memory, *mismatches (host) = offending elements; SR3_E_UNSUPPORTED when it is not 0.
+ * (No reference counterpart: the reference computes in IEEE fp32; this guards the claim that the split path is fp32-class.) */
+int sr3_selftest_split3(int* scratch_dev, int* mismatches, void* stream);
 
 /* UNet construction (model/sr3_modules/unet.py:162-233): builds the layer list, the parameter
  * table and the activation plan.  No device work. */

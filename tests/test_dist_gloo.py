@@ -181,6 +181,35 @@ def test_bench_refuses_inconsistent_rank_counts():
     assert r.returncode == 2 and b'WORLD_SIZE=4' in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-300:])
 
 
+def test_bench_two_ranks_end_to_end_stub_engine():
+    """`python bench.py --gpus 2` end to end on CPU (SR3_BENCH_STUB=1: gloo instead of RCCL, the engine replaced by stand-ins;
+    the launcher, the rank checks, the barrier / MAX-over-ranks timing, the record and the training leg's tail-first bucket
+    walk over the REAL parameter count are the code the driver's 8-GPU run takes): one JSON line with n_gpus 2, global batch
+    32, and a training leg whose gradient arena really was summed over both ranks, 13 buckets per step."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['SR3_BENCH_STUB'] = '1'
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '5', '--warmup', '2', '--train-steps', '2', '--train-batch', '2',
+                        '--no-roofline', '--no-exact-leg', '--no-cpu-baseline', '--no-torch-baseline', '--no-other-configs'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd='/tmp')
+    assert r.returncode == 0, r.stderr[-600:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-600:]                      # rank 0 prints, rank 1 does not
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 5 and rec['warmup'] == 2 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 32 and rec['config']['batch_per_gpu'] == 16
+    assert rec['metric'].startswith('SR3 16->128 images/sec') and rec['unit'] == 'images/s' and rec['higher_is_better'] is True
+    assert abs(rec['value'] - 2 * 16 / (2000 * rec['ms_per_step'] * 1e-3)) < 1e-6 * rec['value']      # whole-job aggregate
+    assert rec['data'].startswith('STUB')                       # a stub line can never pass for a measurement
+    tr = rec['train']
+    assert tr['stub'] and tr['global_batch'] == 4 and tr['batch_per_gpu'] == 2 and tr['steps'] == 2
+    assert tr['gradient_buckets_per_step'] == 12 and tr['gradient_buckets_walked'] == 12 * (2 + 2)     # 391 MB in 32 MB buckets
+    assert tr['l_pix_last'] == 2.0                               # every gradient is 1.0 on each rank: the all-reduce summed them
+    assert abs(tr['value'] - 2 * 2 / (tr['ms_per_step'] * 1e-3)) < 1e-6 * tr['value']
+
+
 def _valwave_worker(rank, world, port, shapes, ret):
     sys.path.insert(0, PKG)
     import torch.distributed as dist

@@ -694,6 +694,16 @@ def test_q_sample_bit_exact():
     assert torch.equal(out.cpu(), ref)
 
 
+def test_split3_selftest():
+    """The device self-test of split3_pair (the shipped form depends on register-resident selector constants and on
+    v_dot2c_f32_bf16's exact result): 2^21 fp32 patterns, every one must equal h + m + l bit for bit."""
+    import ctypes as C
+    scratch = torch.zeros(1, dtype=torch.int32, device=G.dev())
+    bad = C.c_int(-1)
+    L.check(L.load().sr3_selftest_split3(L.ptr(scratch), C.byref(bad), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert bad.value == 0
+
+
 def test_error_convention():
     lib = L.load()
     d = G.dev()
