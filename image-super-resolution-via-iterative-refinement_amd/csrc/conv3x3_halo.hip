@@ -564,10 +564,16 @@ int conv3x3_halo_forward(const ConvParams& p, int cfg, const HaloGeom& g, hipStr
       if (p.drop_thresh != 0)
         return p.x2_w ? launch_halo<4, 2, true, true, 0, 1>(p, g, st) : launch_halo<4, 2, false, true, 0, 1>(p, g, st);
       return launch_halo_x<4, 1, 0>(p, g, st);
-    case 7: return launch_halo_x<2, 2, 1>(p, g, st);    // opt-in 3 x bf16 split MFMA (inference only)
+#ifdef SR3_EXPERIMENTS
+    case 7: return launch_halo_x<2, 2, 1>(p, g, st);    // opt-in 3 x bf16 split MFMA (inference only; plan option split_bf16)
     case 8: return launch_halo_x<4, 2, 1, 1>(p, g, st);   // 256x64 on 8 waves of 64x32 (the 4-wave 64x64 form spills)
-    case 9: return launch_halo_x<4, 2, 0>(p, g, st);    // 8 waves, one workgroup per CU
     case 10: return launch_halo_x<4, 2, 1>(p, g, st);
+#else
+    case 7: case 8: case 10:      // round 1's split form of the direct kernels: superseded by the Winograd / im2col SPLIT instantiations
+      set_error("conv: the split_bf16 halo tiles (7, 8, 10) are an experiment: build with -DSR3_EXPERIMENTS");
+      return SR3_E_UNSUPPORTED;
+#endif
+    case 9: return launch_halo_x<4, 2, 0>(p, g, st);    // 8 waves, one workgroup per CU
   }
   set_error("conv: bad halo tile_cfg %d", cfg);
   return SR3_E_BADARG;

@@ -24,6 +24,15 @@
 
 #include "sr3_common.h"
 
+#ifndef SR3_EXPERIMENTS
+// default build: the experiment is not compiled (csrc/build.sh -DSR3_EXPERIMENTS brings it back, with the opt-in halo split tiles)
+namespace sr3 {
+int conv3x3_wino4_forward(const ConvParams&, const WinoGeom&, const float*, hipStream_t) {
+  set_error("conv: the four-wave split Winograd kernel (tile 13 / plan option wino4) is an experiment: build with -DSR3_EXPERIMENTS");
+  return SR3_E_UNSUPPORTED;
+}
+}  // namespace sr3
+#else
 namespace sr3 {
 
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
@@ -595,3 +604,5 @@ int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* u
 }
 
 }  // namespace sr3
+
+#endif  // SR3_EXPERIMENTS

@@ -953,7 +953,9 @@ int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out) {
   if (!desc || !out) { set_error("null argument"); return SR3_E_BADARG; }
   sr3_plan* P = new (std::nothrow) sr3_plan();
   if (!P) { set_error("out of host memory"); return SR3_E_NOMEM; }
+#ifdef SR3_EXPERIMENTS
   { const char* e = getenv("SR3_WINO4"); if (e) P->wino4 = atoi(e); }      // A/B knob: default of plan option wino4
+#endif
   P->d = *desc;
   const int rc = build_structure(P);
   if (rc) { delete P; *out = nullptr; return rc; }
@@ -1026,6 +1028,12 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "wino4")) slot = &plan->wino4;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
+#ifndef SR3_EXPERIMENTS
+  if ((slot == &plan->split_bf16 || slot == &plan->wino4) && value != 0) {
+    set_error("option %s selects an experiment kernel that this library was built without (csrc/build.sh -DSR3_EXPERIMENTS)", key);
+    return SR3_E_UNSUPPORTED;
+  }
+#endif
   const int prev = *slot;
   *slot = value;
   plan->built_batch = -1;

@@ -253,18 +253,26 @@ def test_plan_launch_list_no_gpu():
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('gemm_split', 1)
     assert p.op_list(16) == ops
-    # opt-in split mode: same list, only the halo tiles change (5 -> 7 or 10, 6 -> 8, 9 -> 10)
-    p.set_option('split_bf16', 1)
-    ops2 = p.op_list(16)
-    assert len(ops2) == len(ops)
-    for a, b in zip(ops, ops2):
-        assert a['kind'] == b['kind'] and a['flops'] == b['flops']
-        if a['kind'] == 50 and 5 <= a['tile_cfg'] <= 10:
-            assert b['tile_cfg'] in {5: (7, 10), 6: (8,), 9: (10,)}[a['tile_cfg']], (a, b)
-        else:
-            assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
-    p.set_option('split_bf16', 0)
-    assert p.op_list(16) == ops
+    from helpers import experiments_built
+    from sr3_hip import lib as L
+    if experiments_built():
+        # opt-in split mode: same list, only the halo tiles change (5 -> 7 or 10, 6 -> 8, 9 -> 10)
+        p.set_option('split_bf16', 1)
+        ops2 = p.op_list(16)
+        assert len(ops2) == len(ops)
+        for a, b in zip(ops, ops2):
+            assert a['kind'] == b['kind'] and a['flops'] == b['flops']
+            if a['kind'] == 50 and 5 <= a['tile_cfg'] <= 10:
+                assert b['tile_cfg'] in {5: (7, 10), 6: (8,), 9: (10,)}[a['tile_cfg']], (a, b)
+            else:
+                assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
+        p.set_option('split_bf16', 0)
+        assert p.op_list(16) == ops
+    else:        # the default build refuses the options that select experiment kernels
+        with pytest.raises(L.Sr3Error) as ei:
+            p.set_option('split_bf16', 1)
+        assert 'SR3_EXPERIMENTS' in str(ei.value)
+        assert p.op_list(16) == ops
     # batch 1: everything is small-M
     assert all(o['tile_cfg'] != 9 or o['h_out'] >= 128 for o in p.op_list(1) if o['kind'] == 50)
 

@@ -414,6 +414,7 @@ def test_gemm_split_stress_absolute_bound(case, ksplit, tile):
     assert ratio <= 1.0, ratio
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('K', [(64, 0), (512, 0), (512, 512)], ids=['K576', 'K4608', 'K9216'])
 def test_split_bf16_error_is_fp32_class(K):
     """The opt-in split-bf16 instantiations (tile 7 / 10) against a float64 reference: their error must be of the

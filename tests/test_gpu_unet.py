@@ -48,6 +48,7 @@ def test_unet_forward_and_layer_taps(name, fuse):
     G.assert_close(eps.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps')
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('name', NAMES)
 def test_unet_forward_split_bf16_option(name):
     """Opt-in `split_bf16` plan option (3 x bf16 operand split on the bf16 MFMA): same stated tolerance."""
