@@ -531,7 +531,9 @@ def headline_dtype(plan, batch):
     conv on a 3 x bf16 split instantiation (Winograd 12 / 13, im2col 14-21, the opt-in halo tiles 7 / 8 / 10) -> the split
     label, none -> plain f32."""
     split_tiles = {7, 8, 10, 12, 13} | set(range(14, 22))
-    return 'f32 via 3xbf16 split MFMA' if any(o['tile_cfg'] in split_tiles for o in plan.op_list(batch)) else 'f32'
+    ops = plan.op_list(batch)
+    attn = any(o['kind'] == 60 for o in ops) and getattr(plan, 'options', {}).get('attn_split', 1) != 0      # (default on)
+    return 'f32 via 3xbf16 split MFMA' if attn or any(o['tile_cfg'] in split_tiles for o in ops) else 'f32'
 
 
 def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=False, plan_opts=None):
@@ -556,6 +558,7 @@ def build_sampler(cfg_name, B, dev, rank, split_bf16=False, T=2000, exact_fp32=F
     if exact_fp32:
         netG.denoise_fn.plan.set_option('wino_split', 0)
         netG.denoise_fn.plan.set_option('gemm_split', 0)
+        netG.denoise_fn.plan.set_option('attn_split', 0)
     for k, v in (plan_opts or {}).items():               # A/B runs only (--plan-opt); the record carries them in `config`
         netG.denoise_fn.plan.set_option(k, v)
     S = cfg['size']
@@ -867,7 +870,7 @@ def main():
             rec['roofline'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0 and not a.no_exact_leg and not a.split_bf16 and not a.exact_fp32:
         try:       # the same step with every conv on the exact-fp32 MFMA instantiations (plan options wino_split = gemm_split = 0)
-            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option=('wino_split', 'gemm_split'), value=0,
+            rec['exact_fp32'] = split_bf16_leg(netG, st, T, dev, option=('wino_split', 'gemm_split', 'attn_split'), value=0,
                                                with_roofline=not a.no_roofline)
             rec['exact_fp32']['dtype'] = 'f32 (v_mfma_f32_32x32x2_f32 everywhere)'
         except Exception as e:                     # the secondary leg must never cost the headline line

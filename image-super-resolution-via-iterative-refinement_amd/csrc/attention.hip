@@ -222,7 +222,12 @@ template <> struct AtVec<4> { typedef f32x4 type; };
 template <int TN> __device__ __forceinline__ float at_elem(const typename AtVec<TN>::type& v, int t) { return v[t]; }
 template <> __device__ __forceinline__ float at_elem<1>(const float& v, int) { return v; }
 
-template <int KP, int TN>
+// SPLIT (round 5; plan option attn_split): both contractions on v_mfma_f32_32x32x16_bf16 with every fp32 operand as three bf16
+// terms and six products per fp32 product, fp32 accumulation -- the arithmetic of the SPLIT conv kernels (fp32-class results,
+// gated against float64 in tests/).  A lane's operand is then 8 consecutive k of its row: 32 contiguous bytes of its query / key
+// row (phase 1), 8 probabilities of the strip and 8 keys' worth of its TN channels (phase 3), split in registers; D = 2 groups
+// of 16 k in flight.
+template <int KP, int TN, bool SPLIT>
 __global__ __launch_bounds__(256) void k_attention_v2(const float* __restrict__ qkv, int B, int N, int C, int zsplit,
                                                        float* __restrict__ out) {
   extern __shared__ f32x4 smem_v[];
@@ -248,7 +253,59 @@ __global__ __launch_bounds__(256) void k_attention_v2(const float* __restrict__ 
   constexpr int D = 4;                                      // operand groups in flight
 
   // ---------------- phase 1 ----------------
-  {
+  if constexpr (SPLIT) {
+    const int KB = N >> 5, G = C >> 4;                      // groups of 16 channels = one bf16 MFMA k-step; G % 2 == 0 (C % 128 == 0)
+    const int k8 = (lane >> 5) * 8;
+    const float* qrow = base + (size_t)(m0 + ln) * rowstride + k8;
+    constexpr int DS = 2;
+    for (int kb0 = wave * KP; kb0 < KB; kb0 += 4 * KP) {
+      const float* krow[KP];
+#pragma unroll
+      for (int p = 0; p < KP; ++p) krow[p] = base + (size_t)(min(kb0 + p, KB - 1) * 32 + ln) * rowstride + C + k8;
+      f32x16 acc[KP];
+#pragma unroll
+      for (int p = 0; p < KP; ++p)
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) acc[p][r_] = 0.f;
+      f32x4 a[DS][2], k4[DS][KP][2];
+#pragma unroll
+      for (int d = 0; d < DS; ++d)
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          a[d][hlf] = *reinterpret_cast<const f32x4*>(qrow + d * 16 + hlf * 4);
+#pragma unroll
+          for (int p = 0; p < KP; ++p) k4[d][p][hlf] = *reinterpret_cast<const f32x4*>(krow[p] + d * 16 + hlf * 4);
+        }
+      for (int g0 = 0; g0 < G; g0 += DS) {
+#pragma unroll
+        for (int d = 0; d < DS; ++d) {
+          bf16x8 qa[3];
+          split3x8(a[d][0], a[d][1], qa[0], qa[1], qa[2]);
+#pragma unroll
+          for (int p = 0; p < KP; ++p) {
+            bf16x8 kb[3];
+            split3x8(k4[d][p][0], k4[d][p][1], kb[0], kb[1], kb[2]);
+            mfma_split6(qa, kb, acc[p]);
+          }
+          const int gn = min(g0 + d + DS, G - 1) * 16;        // (the tail re-fetches the last group: the loads stay unconditional)
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf) {
+            a[d][hlf] = *reinterpret_cast<const f32x4*>(qrow + gn + hlf * 4);
+#pragma unroll
+            for (int p = 0; p < KP; ++p) k4[d][p][hlf] = *reinterpret_cast<const f32x4*>(krow[p] + gn + hlf * 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < KP; ++p) {
+        if (kb0 + p < KB) {
+          const int key = (kb0 + p) * 32 + ln;
+#pragma unroll
+          for (int r_ = 0; r_ < 16; ++r_) S[((r_ & 3) + 8 * (r_ >> 2) + kh) * LDS_S + key] = acc[p][r_] / sqrt_c;
+        }
+      }
+    }
+  } else {
     const int KB = N >> 5, G = C >> 3;                      // G % D == 0 (C % 32 == 0: host)
     const float* qrow = base + (size_t)(m0 + ln) * rowstride + kh;
     for (int kb0 = wave * KP; kb0 < KB; kb0 += 4 * KP) {
@@ -315,33 +372,68 @@ __global__ __launch_bounds__(256) void k_attention_v2(const float* __restrict__ 
     typedef typename AtVec<TN>::type vec_t;
     const int Cz = C / zsplit;
     const int cz0 = zi * Cz;
-    const int G = N >> 3;                                     // G % D == 0 (N % 32 == 0)
+    [[maybe_unused]] const int G = N >> 3;                    // G % D == 0 (N % 32 == 0)
     for (int cw = wave * 32 * TN; cw < Cz; cw += 4 * 32 * TN) {
       const int c0 = cz0 + cw;
-      const float* vcol = base + 2 * C + c0 + TN * ln + (size_t)kh * rowstride;       // key kh, this lane's TN channels
-      const float* prow = S + ln * LDS_S + kh;
       f32x16 acc[TN];
 #pragma unroll
       for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int r_ = 0; r_ < 16; ++r_) acc[t][r_] = 0.f;
-      vec_t vb[D][4];
+      if constexpr (SPLIT) {
+        const int k8 = (lane >> 5) * 8;
+        const int G16 = N >> 4;                               // groups of 16 keys; G16 % 2 == 0 (N % 32 == 0)
+        constexpr int DS = 2;
+        const float* vcol = base + 2 * C + c0 + TN * ln + (size_t)k8 * rowstride;     // key k8, this lane's TN channels
+        const float* prow = S + ln * LDS_S + k8;
+        vec_t vb[DS][8];
 #pragma unroll
-      for (int d = 0; d < D; ++d)
+        for (int d = 0; d < DS; ++d)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + (size_t)(d * 8 + q) * rowstride);
-      for (int g0 = 0; g0 < G; g0 += D) {
+          for (int q = 0; q < 8; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + (size_t)(d * 16 + q) * rowstride);
+        for (int g0 = 0; g0 < G16; g0 += DS) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(prow + (g0 + d) * 8);
+          for (int d = 0; d < DS; ++d) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(prow + (g0 + d) * 16);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(prow + (g0 + d) * 16 + 4);
+            bf16x8 pa[3];
+            split3x8(p0, p1, pa[0], pa[1], pa[2]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int t = 0; t < TN; ++t) {
+              const f32x4 v0 = {at_elem<TN>(vb[d][0], t), at_elem<TN>(vb[d][1], t), at_elem<TN>(vb[d][2], t), at_elem<TN>(vb[d][3], t)};
+              const f32x4 v1 = {at_elem<TN>(vb[d][4], t), at_elem<TN>(vb[d][5], t), at_elem<TN>(vb[d][6], t), at_elem<TN>(vb[d][7], t)};
+              bf16x8 vv[3];
+              split3x8(v0, v1, vv[0], vv[1], vv[2]);
+              mfma_split6(pa, vv, acc[t]);
+            }
+            const size_t kn = (size_t)(min(g0 + d + DS, G16 - 1) * 16) * rowstride;
 #pragma unroll
-            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], at_elem<TN>(vb[d][q], t), acc[t], 0, 0, 0);
-          const size_t kn = (size_t)(min(g0 + d + D, G - 1) * 8) * rowstride;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + kn + (size_t)q * rowstride);
+            for (int q = 0; q < 8; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + kn + (size_t)q * rowstride);
+          }
         }
+      }
+      if constexpr (!SPLIT) {
+        const float* vcol = base + 2 * C + c0 + TN * ln + (size_t)kh * rowstride;       // key kh, this lane's TN channels
+        const float* prow = S + ln * LDS_S + kh;
+        vec_t vb[D][4];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + (size_t)(d * 8 + q) * rowstride);
+        for (int g0 = 0; g0 < G; g0 += D) {
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(prow + (g0 + d) * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], at_elem<TN>(vb[d][q], t), acc[t], 0, 0, 0);
+            const size_t kn = (size_t)(min(g0 + d + D, G - 1) * 8) * rowstride;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vb[d][q] = *reinterpret_cast<const vec_t*>(vcol + kn + (size_t)q * rowstride);
+          }
+        }
+  
       }
       float* orow = out + ((size_t)b * N + m0) * C + c0 + TN * ln;
 #pragma unroll
@@ -360,19 +452,24 @@ __global__ __launch_bounds__(256) void k_attention_v2(const float* __restrict__ 
 }
 
 namespace {
-template <int KP, int TN>
-int launch_attention_v2(const float* qkv, int B, int N, int C, int zsplit, float* out, hipStream_t st) {
+template <int KP, int TN, bool SPLIT>
+int launch_attention_v2s(const float* qkv, int B, int N, int C, int zsplit, float* out, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
   const int smem = 32 * (N + 4) * (int)sizeof(float);
-  auto kern = k_attention_v2<KP, TN>;
+  auto kern = k_attention_v2<KP, TN, SPLIT>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024, done)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)((N / 32) * B * zsplit)), dim3(256), smem, st, qkv, B, N, C, zsplit, out);
   SR3_LAUNCH_CHECK("k_attention_v2");
   return SR3_OK;
 }
+template <int KP, int TN>
+int launch_attention_v2(const float* qkv, int B, int N, int C, int zsplit, float* out, hipStream_t st, bool split) {
+  return split ? launch_attention_v2s<KP, TN, true>(qkv, B, N, C, zsplit, out, st)
+               : launch_attention_v2s<KP, TN, false>(qkv, B, N, C, zsplit, out, st);
+}
 }  // namespace
 
-int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st) {
+int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st, int split) {
   if (C & 3) { set_error("attention: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   if ((double)B * N * 3.0 * C >= 2147483647.0) { set_error("attention: qkv exceeds 2^31 elements"); return SR3_E_UNSUPPORTED; }
   // the staging-free kernel wherever the shape allows it (SR3_ATTN_V1=1, read once: A/B knob for the profiles)
@@ -385,13 +482,13 @@ int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStre
     const int tn = (Cz % 512 == 0) ? 4 : ((Cz % 256 == 0) ? 2 : 1);
     const bool pairs = N / 32 >= 8;                       // two key blocks per wave and round share the Q fragment
     if (pairs) {
-      if (tn == 4) return launch_attention_v2<2, 4>(qkv, B, N, C, zsplit, out, st);
-      if (tn == 2) return launch_attention_v2<2, 2>(qkv, B, N, C, zsplit, out, st);
-      return launch_attention_v2<2, 1>(qkv, B, N, C, zsplit, out, st);
+      if (tn == 4) return launch_attention_v2<2, 4>(qkv, B, N, C, zsplit, out, st, split != 0);
+      if (tn == 2) return launch_attention_v2<2, 2>(qkv, B, N, C, zsplit, out, st, split != 0);
+      return launch_attention_v2<2, 1>(qkv, B, N, C, zsplit, out, st, split != 0);
     }
-    if (tn == 4) return launch_attention_v2<1, 4>(qkv, B, N, C, zsplit, out, st);
-    if (tn == 2) return launch_attention_v2<1, 2>(qkv, B, N, C, zsplit, out, st);
-    return launch_attention_v2<1, 1>(qkv, B, N, C, zsplit, out, st);
+    if (tn == 4) return launch_attention_v2<1, 4>(qkv, B, N, C, zsplit, out, st, split != 0);
+    if (tn == 2) return launch_attention_v2<1, 2>(qkv, B, N, C, zsplit, out, st, split != 0);
+    return launch_attention_v2<1, 1>(qkv, B, N, C, zsplit, out, st, split != 0);
   }
   const int Npad = (N + 31) & ~31;
   const size_t strip = (size_t)32 * (Npad + 4);

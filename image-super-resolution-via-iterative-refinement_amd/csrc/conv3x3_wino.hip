@@ -116,16 +116,6 @@ __device__ __forceinline__ float silu_w(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 #endif
 }
-// x = h + m + l with three bf16 terms (8 + 8 + 8 significant bits, each residual exact in fp32) for the eight values a lane
-// contributes to one v_mfma_f32_32x32x16_bf16 operand
-__device__ __forceinline__ void split3x8(const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    bf16x2 hh, mm, ll;
-    split3_pair(e < 4 ? lo[e] : hi[e - 4], e < 4 ? lo[e + 1] : hi[e - 3], hh, mm, ll);       // (sr3_common.h)
-    h[e] = hh[0]; h[e + 1] = hh[1]; m[e] = mm[0]; m[e + 1] = mm[1]; l[e] = ll[0]; l[e + 1] = ll[1];
-  }
-}
 constexpr int WUS = 3 * 64 * 8;          // SPLIT: bf16 elements of one (position, n block) fragment group: 3 planes x 64 lanes x 8
 }  // namespace
 
@@ -432,7 +422,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
                                        (__attribute__((address_space(3))) void*)(zone + (z * WHI + j) * WNT + wave * 64), 16, 0, 0);
     }
   };
-  auto zone_read = [&](f32x4 (&r)[WHI], int z, int j0 = 0, int j1 = GE::WHI) {
+  [[maybe_unused]] auto zone_read = [&](f32x4 (&r)[WHI], int z, int j0 = 0, int j1 = GE::WHI) {
     int t_ = tid;
     asm volatile("" : "+v"(t_));
 #pragma unroll
@@ -443,7 +433,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   };
   // GroupNorm (scale, shift) of the tile's image for the channels of this workgroup's chunk range live in LDS (cst + 64 of the
   // tile's parity): the staging step reads its 4 channels' pairs from there instead of keeping 8 registers live across a chunk
-  auto load_pairs = [&](int chunk, const float* cs_, f32x4 (&ss)[2]) {       // (one-image tile) the staging step's pairs, read ahead
+  [[maybe_unused]] auto load_pairs = [&](int chunk, const float* cs_, f32x4 (&ss)[2]) {       // (one-image tile) the staging step's pairs, read ahead
     ss[0] = f32x4{0.f, 0.f, 0.f, 0.f}; ss[1] = ss[0];
     if (p.act != 0) {
       int kq_ = kq;
@@ -667,7 +657,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // static priority for the second-dispatched half of the workgroup (the arbitration loser on every SIMD)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-  int gseq = 0;                                      // SPLIT ping-pong loop: MFMA clusters this wave has issued (kernel lifetime)
+  [[maybe_unused]] int gseq = 0;                                      // SPLIT ping-pong loop: MFMA clusters this wave has issued (kernel lifetime)
   if (SPLIT && SR3_WINO_PP && SR3_PP_TOKEN && tid < 8)
     reinterpret_cast<int*>(smem + W_TOK_F)[tid] = 0;       // (the first barrier below)
   // ---- first tile: constants, raw chunks 0 and 1 ------------------------------------------------------------------

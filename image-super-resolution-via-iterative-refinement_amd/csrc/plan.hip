@@ -770,7 +770,7 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
       }
       case OP_ATTN:
         rc = attention_forward(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1,
-                               reinterpret_cast<float*>(ws + o.b), st);
+                               reinterpret_cast<float*>(ws + o.b), st, P->attn_split);
         break;
       case OP_CONV_OUT:
         rc = conv_out_nchw(reinterpret_cast<const float*>(ws + o.a), reinterpret_cast<const float*>(ws + R.ss_off + o.ss_rel),
@@ -1022,6 +1022,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
   else if (!strcmp(key, "wino_split8")) slot = &plan->wino_split8;
+  else if (!strcmp(key, "attn_split")) { const int prev = plan->attn_split; plan->attn_split = value; return prev; }   // no rebuild
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
@@ -1372,6 +1373,10 @@ int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* st
 int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream) {
   if (!qkv || !out) { set_error("null argument"); return SR3_E_BADARG; }
   return attention_forward(qkv, B, N, C, out, static_cast<hipStream_t>(stream));
+}
+int sr3_attention_ex_f32(const float* qkv, int B, int N, int C, float* out, int split, void* stream) {
+  if (!qkv || !out) { set_error("null argument"); return SR3_E_BADARG; }
+  return attention_forward(qkv, B, N, C, out, static_cast<hipStream_t>(stream), split);
 }
 int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep, const float* freq,
                        const float* w1, const float* b1, const float* w2, const float* b2, const float* wf,

@@ -54,6 +54,22 @@ __device__ __forceinline__ void split3(const f32x4 v, bf16x4& h, bf16x4& m, bf16
   }
 }
 
+// ... for the eight values a lane contributes to one v_mfma_f32_32x32x16_bf16 operand (k = 0..3 from lo, 4..7 from hi)
+__device__ __forceinline__ void split3x8(const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    bf16x2 hh, mm, ll;
+    split3_pair(e < 4 ? lo[e] : hi[e - 4], e < 4 ? lo[e + 1] : hi[e - 3], hh, mm, ll);
+    h[e] = hh[0]; h[e + 1] = hh[1]; m[e] = mm[0]; m[e + 1] = mm[1]; l[e] = ll[0]; l[e + 1] = ll[1];
+  }
+}
+// six bf16 MFMA products of the split operands (a = a_h + a_m + a_l, b likewise), smallest terms first: a.b up to terms <= 2^-24 of it
+__device__ __forceinline__ void mfma_split6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& acc) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b[PB[q]], acc, 0, 0, 0);
+}
+
 // sigmoid / SiLU of the staging and activation-backward steps: libm expf (1 ulp) and the hardware reciprocal v_rcp_f32
 // (1 ulp).  Measured against float64 autograd at batch 64 (profiles/r04_grad_probe.txt): parameter gradients are within 5e-7
 // of float64 with these, the same as with an IEEE division (-DSR3_EXACT_ACT, A/B builds only) and as stock PyTorch-ROCm.
@@ -258,7 +274,8 @@ struct EmbedParams {
 };
 int embed_forward(const EmbedParams& p, hipStream_t st);
 // single-head attention over NHWC qkv [B][N][3C] -> out [B][N][C]
-int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st);
+// split != 0: the staging-free kernel's 3 x bf16 split instantiation where the shape takes that kernel (fp32 MFMA otherwise)
+int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st, int split = 0);
 // fused reverse-step update (NCHW, elementwise): coef = {a, b, c1, c2, sigma} tables of length T
 struct StepTables { const float* a; const float* b; const float* c1; const float* c2; const float* sigma; };
 int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,

@@ -93,6 +93,7 @@ SIGNATURES = {
     'sr3_conv_stats_slices': (_I, [_I, _I, _I, _I, _I, _I, _I, _I]),
     'sr3_groupnorm_fold_f32': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _P, _P, C.c_float, _P, _P]),
     'sr3_attention_f32': (_I, [_P, _I, _I, _I, _P, _P]),
+    'sr3_attention_ex_f32': (_I, [_P, _I, _I, _I, _P, _I, _P]),
     'sr3_film_embed_f32': (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P]),
     'sr3_conv_in_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     'sr3_conv_out_f32': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),

@@ -286,6 +286,9 @@ int sr3_groupnorm_fold_f32(const double* stat0, int C0, int T0, const double* st
                            int groups, const float* gamma, const float* beta, float eps, float* ss, void* stream);
 /* SelfAttention core (unet.py:127-139): qkv NHWC [B][N][3C] -> out [B][N][C] */
 int sr3_attention_f32(const float* qkv, int B, int N, int C, float* out, void* stream);
+/* ... with split != 0: QK^T and PV as six bf16 MFMA products of 3-way split fp32 operands, fp32 accumulation (plan option
+ * attn_split; fp32-class results, gated against float64 in tests/), where the shape takes the staging-free kernel */
+int sr3_attention_ex_f32(const float* qkv, int B, int N, int C, float* out, int split, void* stream);
 /* backward of the attention core (autograd of unet.py:127-139): dqkv [B][N][3C] from qkv, d(out) [B][N][C]; out_fwd
  * (the forward output) may be NULL when N <= ~480 -- larger N use a key-blocked pass that reads it */
 int sr3_attention_bwd_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,

