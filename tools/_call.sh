@@ -1,4 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "attention" -s 2>&1 | grep -E "attention B|passed|failed|Error|assert" | head -30
-timeout 120 python tools/op_table.py 2>/dev/null | tail -12
-timeout 120 python tools/op_table.py --opt attn_split=0 2>/dev/null | grep "#   60"
+Q="--steps 300 --warmup 10 --no-cpu-baseline --no-torch-baseline --train-steps 0 --no-other-configs --no-exact-leg --no-roofline"
+for o in 1 0 1 0; do
+timeout 200 python bench.py $Q --plan-opt conv_fold=$o 2>/dev/null | python -c "import sys,json; print('conv_fold=$o', json.loads(sys.stdin.read())['ms_per_step'])"
+done
