@@ -151,8 +151,9 @@ def test_committed_profile_summaries_cover_the_kernels_bench_reports():
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_sq_counters.json')) as f:
         sq = json.load(f)
     for sym in ('sr3::k_conv3x3_wino<0, false, false, true>', 'sr3::k_conv3x3_wino<0, false, false, false>',
-                'sr3::k_conv_igemm<64, 64, 1, true>', 'sr3::k_conv_igemm<64, 64, 1, false>'):
-        assert 2e7 < traffic[sym]['hbm_bytes_per_launch'] < 1e9, (sym, traffic.get(sym))
+                'sr3::k_conv_igemm<64, 64, 1, 1>', 'sr3::k_conv_igemm<64, 64, 1, 0>',
+                'sr3::k_conv3x3_wino<0, false, true, true>', 'sr3::k_attention_v2<2, 2, true>'):
+        assert 5e6 < traffic[sym]['hbm_bytes_per_launch'] < 1e9, (sym, traffic.get(sym))
         assert 0.05 < sq[sym]['mfma_busy'] < 1.0, (sym, sq.get(sym))
     # the stats file the bench line's avg launch time must agree with
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_bench_kernel_stats.csv')) as f:
