@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
 
 // ---------------------------------------------------------------------------------------------------------------
 // Round 3: the same computation with NO operand staging -- every MFMA operand except the probabilities comes straight from
-// global memory in fragment form, because on this part nothing overlaps the fp32 MFMA (profiles/r03_mfma_overlap.txt), so
+// global memory in fragment form, because on this part nothing overlaps the fp32 MFMA (profiles/archive/r03_mfma_overlap.txt), so
 // the cheapest operand is the one that costs the fewest instructions:
 //   phase 1  S = Q K^T / sqrt(C): a lane's A / B operand for 4 consecutive k-steps is 16 contiguous bytes of ITS query /
 //            key row (qkv is channel-contiguous), i.e. one global_load_dwordx4; a key block belongs to exactly one wave, so

@@ -3,7 +3,7 @@
 // v_mfma_f32_32x32x2_f32, organised around an LDS-resident *activated halo tile*.
 //
 // Why not plain im2col staging (conv_igemm.hip): on gfx950 the exact-fp32 MFMA runs at the fp32
-// VALU rate and, measured with rocprofv3 (profiles/r01_*), VALU work does not overlap it -- every
+// VALU rate and, measured with rocprofv3 (profiles/archive/r01_*), VALU work does not overlap it -- every
 // VALU instruction spent on staging is MFMA time lost.  With im2col staging each input element is
 // loaded, GroupNorm-scaled and SiLU'd once per filter tap (9x); here a workgroup owns a spatial
 // output tile (TH x TW pixels of NB images), stages the (TH+2) x (TW+2) input halo of one 32-channel

@@ -4,7 +4,7 @@
 // :58-65, the skip concat :255) with 2.25x fewer multiplies: on gfx950 the fp32 MFMA runs at the fp32 vector rate
 // (157 TF), so the contraction is MFMA-bound and the only way past that roof in fp32 is to multiply less.  Stock
 // PyTorch-ROCm does the same for this network (MIOpen picks miopenSp3AsmConv_*_fp32_f2x3 / f3x2 Winograd kernels,
-// profiles/r02_torch_rocm_kernel_stats.csv), i.e. this is also the arithmetic the reference itself runs on a GPU.
+// profiles/archive/r02_torch_rocm_kernel_stats.csv), i.e. this is also the arithmetic the reference itself runs on a GPU.
 // fp32 error of F(2x2,3x3) is of the direct convolution's order (transforms with coefficients 0, +-1, +-1/2 only):
 // whole-UNet max error vs float64 1.35e-6 against 1.17e-6 for direct fp32 (tests/test_gpu_ops.py).
 //
@@ -14,7 +14,7 @@
 //   M_ij[tile][n] = sum_c V_ij[tile][c] * U_ij[n][c],   tile = 2x2 output block, n = output channel, c = input channel.
 //
 // Workgroup = 8 waves (one per CU: 2 waves / SIMD): 64 Winograd tiles (16x16 output pixels of one image) x 64 output
-// channels x all 16 positions (8x8 maps keep the direct kernel).  Wave w owns transform row i = w >> 1 and the two columns
+// channels x all 16 positions (8 x 8 maps: four images per tile, NB4).  Wave w owns transform row i = w >> 1 and the two columns
 // j = 2 (w & 1), 2 (w & 1) + 1: 2 positions x (64 x 64) outputs = 128 accumulator registers.
 // Per 16-channel chunk of the (virtual concat) input:
 //   1. the raw input halo ((TH+2) x (TW+2) pixels x 16 channels) is staged ONCE by the whole workgroup, GroupNorm
@@ -256,7 +256,7 @@ int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag,
 // GroupNorm / SiLU arithmetic of the staging step, 4 skip the input transforms, 8 skip the epilogue, 16 skip the U loads of the
 // loop, 32 skip the raw staging of the loop, 64 write shader-clock stamps of every tile's phases (tools/wino_phases.py)
 //
-// Memory operations and the in-order vmcnt counter.  Measured on the round-3 phase timeline (profiles/r03d_*): every
+// Memory operations and the in-order vmcnt counter.  Measured on the round-3 phase timeline (profiles/archive/r03d_*): every
 // `s_waitcnt vmcnt(0)` in a tile's prologue / epilogue costs 2-3 k cycles (all CUs hit their tile boundaries together), and
 // the compiler falls back to vmcnt(0) whenever a load sits under a condition or in a loop of unknown length.  So outside the
 // main loop every global load here is UNCONDITIONAL (absent operands are read from a valid dummy address and discarded by a

@@ -4,6 +4,8 @@
 // meant to replace (8.01-8.4 vs 8.08 ms per step, profiles/r04e_wino4_ablations.txt).  The premise below -- that interleaving the
 // staging / transform VALU work with the MFMAs inside one wave hides it -- does not hold on gfx950: VALU instructions do not execute
 // next to an MFMA, whichever wave issues them (profiles/r04g_mfma_overlap_bf16.txt); the loop is 96 MFMAs + ~700 VALU in any order.
+// (Round 5 corrected that rule -- DESIGN.md section 3.1e, profiles/r05a_mfma_fillers.txt: <= 5 plain VALU instructions per MFMA do hide when interleaved, packed
+// f32 / v_dot2c do not, and this kernel's ~7.3 per MFMA with 190 packed ones is over either budget; its LDS round trips are the rest of the story.)
 //
 // Same op, same arithmetic and same derived filters as the SPLIT instantiation of conv3x3_wino.hip (plan option wino_split:
 // every fp32 operand as x = h + m + l, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation); what changes is

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__
     __syncthreads();
     // The filter taps are the same for every lane: they are read through workgroup-uniform addresses, i.e. scalar loads into
     // SGPRs that feed the FMAs directly (round 3; the LDS copy of the weights cost 4 broadcast ds_read_b128 per tile read and
-    // made the kernel LDS-instruction bound: 62 -> measured in profiles/r03*).  Same FMA order as before: (tap, quad, element).
+    // made the kernel LDS-instruction bound: 62 -> measured in profiles/archive/r03*).  Same FMA order as before: (tap, quad, element).
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const float* tp = tile + ((ty + tap / 3) * (OT_W + 2) + tx + tap % 3) * OT_LD;
