@@ -108,10 +108,17 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   0: v_mfma_f32_32x32x2_f32.
  * gemm_tile (default 0 = automatic; A/B runs): force im2col tile 1-4 (128x128 / 128x64 / 64x64 / 64x128) on every convolution of that
  *   kernel -- how profiles/r04f_gemm_split_sweep.txt timed the tiles inside the forward.
- * wino4 (default 0, experimental): wino_split convolutions on the four-wave, 512-register kernel (conv3x3_wino4.hip).
+ * wino_split8 (default 1, round 5): the four-image tile of the 8x8 maps on its 3 x bf16 split instantiation too (no dropout form:
+ *   a training forward's dropout convs on 8x8 maps keep the fp32 MFMA).
+ * gemm_wpre (default 0): the im2col split tiles read their weights pre-split from the derived buffer (tiles 18-21) instead of
+ *   splitting them while staging; measured slower in both layouts tried (profiles/r05b_*), kept as an A/B knob.
+ * attn_split (default 1, round 5): SelfAttention's two contractions (Q K^T, P V) on the 3 x bf16 split instantiation of the
+ *   staging-free kernel, gated against float64 like the convolutions; 0: v_mfma_f32_32x32x2_f32.  No rebuild of the plan.
+ * wino4 (default 0, experimental; needs a library built with -DSR3_EXPERIMENTS, refused otherwise): wino_split convolutions on the
+ *   four-wave, 512-register kernel (conv3x3_wino4.hip).
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
- * split_bf16 (default 0, experimental): run the halo-tile 3x3 convolutions of the inference plan on
+ * split_bf16 (default 0, experimental; needs -DSR3_EXPERIMENTS, refused otherwise): run the halo-tile 3x3 convolutions of the inference plan on
  *   v_mfma_f32_32x32x16_bf16 with every fp32 operand split into three bf16 terms (x = h + m + l) and the six
  *   products hh, hm, mh, mm, hl, lh accumulated in fp32 -- fp32-class accuracy (dropped terms <= 2^-23 of a
  *   product), not the bit pattern of the fp32 MFMA.  Operands are split while they are staged into LDS (a pre-split
