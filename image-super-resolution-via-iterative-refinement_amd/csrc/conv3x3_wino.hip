@@ -744,173 +744,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         split3x8(lo, hi, h, m, l);
       };
 #if SR3_WINO_PP
-      // ---- ping-pong schedule (round 5) --------------------------------------------------------------------------------------
-      // What tools/mfma_fillers.hip measured on gfx950 (profiles/r05c_mfma_fillers.txt): plain VALU work of one wave of a SIMD runs
-      // under the MFMAs of the OTHER wave for free (two waves per SIMD in anti-phase: up to 5 VALU per MFMA cost nothing; with an
-      // s_barrier behind every cluster as the metronome the pair even beats the bare two-wave MFMA stream), while two waves in
-      // lock step -- what one barrier per chunk gives, and what this loop did until round 4 -- add their MFMA and VALU times
-      // (measured then: 7.1 k cycles per chunk against 3.07 k of MFMAs).  So the loop is cut into clusters, MFMA (G: the 12 MFMAs
-      // of one position of one tile block) and VALU (V), a workgroup barrier behind each, and waves 4-7 (the second wave of every
-      // SIMD) run one barrier behind waves 0-3: whenever one wave of a SIMD is in a G cluster the other is in a V cluster.
-      //   G1 (m0, a) | V1: split b (m0) ; transform m1               | G2 (m0, b) | V2: split a (m1) ; stage chunk i + 2
-      //   G3 (m1, a) | V3: split b (m1) ; transform m0 of chunk i + 1 | G4 (m1, b) | V4: split a (m0 of chunk i + 1)
-      // The barriers are also the only synchronisation the raw tiles need: with waves 4-7 one slot late, the last reads of
-      // raw[i & 1] (V1: slots 8 i + 1, 8 i + 2) precede its first overwrite (V2: slots 8 i + 3, 8 i + 4), and chunk i + 1's tile
-      // (complete by slot 8 i) is first read in V3 (8 i + 5).  Operands are built in the cluster in front of their MFMAs and die
-      // with them: one set of planes (12 registers) instead of two, and position b's no longer wait in LDS.
-      {
-        bf16x8 vs[3];
-        const bool late = wave >= 4;                    // (waves w and w + 4 share SIMD w & 3)
-        // position b's transformed values (two quads) wait in LDS from their transform to their split, two clusters later:
-        // [quad][thread], every thread reads what it wrote (8 registers fewer across the staging clusters, whose global loads
-        // would otherwise spill -- a spill reload waits on vmcnt(0), i.e. on every load in flight)
-        f32x4* bpark = zone + 2 * WHI * WNT;
-        auto park_vb = [&]() {
-          if (!SR3_WINO_PARKB) return;
-          int t_ = tid;
-          asm volatile("" : "+v"(t_));
-          bpark[t_] = vb0; bpark[WNT + t_] = vb1;
-        };
-        auto fetch_vb = [&]() {
-          if (!SR3_WINO_PARKB) return;
-          int t_ = tid;
-          asm volatile("" : "+v"(t_));
-          vb0 = bpark[t_]; vb1 = bpark[WNT + t_];
-        };
-        {
-          f32x4 da[3], db[3];
-          t_load(raw0, 0, 0, da, db);
-          t_finish(da, db, va0, vb0);
-          t_load(raw0, 0, 1, da, db);
-          t_finish(da, db, va1, vb1);
-          sp3(va0, va1, vs[0], vs[1], vs[2]);
-          park_vb();
-        }
-        // Cluster barriers.  Behind a VALU cluster: a bare s_barrier -- the LDS reads issued at the cluster's end for the NEXT VALU
-        // cluster (transform rows, parked values, staging items) stay in flight across the barrier and the MFMA cluster, so their
-        // latency is paid by nobody.  Behind an MFMA cluster: lgkmcnt(0) first (those reads are consumed next anyway), which is
-        // also what completes the staging cluster's LDS writes before any other wave can read them (their first reader is a whole
-        // iteration away).  Not __syncthreads(): its release fence makes the compiler wait for the LDS transfers in flight
-        // (vmcnt(0) right behind their issue) -- their only consumer is the issuing thread itself, behind its own vmcnt wait.
-#if SR3_PP_STRICT
-#define SR3_PP_BARRIER_V() do { SR3_SB(); asm volatile("s_barrier" ::: "memory"); SR3_SB(); } while (0)
-#define SR3_PP_BARRIER_G() do { SR3_SB(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); SR3_SB(); } while (0)
-#define SR3_PP_CHUNK_BARRIER(when_late) do {} while (0)
-#else
-        // relaxed form: ONE workgroup barrier per chunk -- what the raw tiles need (behind every wave's last reads of raw[i & 1],
-        // in front of the staging writes) -- placed one cluster earlier for waves 4-7 (in front of G2) than for waves 0-3 (behind
-        // it): between two barriers every wave runs the same eight clusters, but the pairs of a SIMD leave each barrier in
-        // anti-phase (one into an MFMA cluster, one into a VALU cluster) and run free from there
-#define SR3_PP_BARRIER_V() SR3_SB()
-#define SR3_PP_BARRIER_G() SR3_SB()
-#define SR3_PP_CHUNK_BARRIER(when_late) do { if (late == (when_late)) { SR3_SB(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); SR3_SB(); } } while (0)
-#endif
-        // MFMA hand-off between the two waves of a SIMD (w and w + 4).  Left alone the pair falls into lock step -- both in their
-        // MFMA clusters together (the pipe serialises them: 2 x 12 MFMAs before either goes on), then both in their VALU
-        // clusters -- and a chunk costs 4 (2 G + V).  With the order G(w), G(w + 4), G(w), ... enforced, each wave's VALU cluster
-        // runs beside the other's MFMAs and the other's VALU cluster: 4 (G + V).  Two counters per pair in LDS, one writer each:
-        // clusters issued so far; a wave waits (ds_read + s_sleep) until its partner has issued the cluster in front of its own.
-#if SR3_PP_TOKEN
-        typedef volatile __attribute__((address_space(3))) int* lds_flag_t;       // (explicitly LDS: a generic volatile access is a flat one, vmcnt(0) and all)
-        lds_flag_t tokens = (lds_flag_t)(smem + W_TOK_F);                         // [2][4]: waves 0-3, waves 4-7
-        auto tok_wait = [&]() {
-          const int need = late ? gseq + 1 : gseq;
-          lds_flag_t f = tokens + (late ? 0 : 4) + (wave & 3);
-          while (__builtin_amdgcn_readfirstlane(*f) < need) __builtin_amdgcn_s_sleep(1);
-        };
-        auto tok_done = [&]() {
-          ++gseq;
-          if (lane == 0) tokens[(late ? 4 : 0) + (wave & 3)] = gseq;
-        };
-#else
-        auto tok_wait = [&]() {};
-        auto tok_done = [&]() {};
-#endif
-        constexpr bool PF = (SR3_PP_PREFETCH & 1) != 0, PFS = (SR3_PP_PREFETCH & 2) != 0;     // transform rows / staging reads
-        f32x4 da[3], db[3];                      // row reads of the next transform's first half (PF: in flight across an MFMA cluster)
-        f32x4 rz[WHI], ssq[2];                   // staging: raw items out of the landing zone, GroupNorm pairs -- likewise
-        auto pre_T = [&](const float* rb, int m) { fetch_vb(); t_load(rb, m, 0, da, db); };
-        auto do_T = [&](const float* rb, int m) {              // split b of the current unit ; transform of the next one
-          if (!PF) pre_T(rb, m);
-          f32x4 ta = va0, tb = vb0;
-          t_finish(da, db, ta, tb);
-          t_load(rb, m, 1, da, db);
-          sp3(vb0, vb1, vs[0], vs[1], vs[2]);
-          t_finish(da, db, va1, vb1);
-          va0 = ta; vb0 = tb;
-          park_vb();
-        };
-        auto pre_S = [&](int chunk, int z, int j0, int j1) {
-          zone_read(rz, z, j0, j1);
-          fetch_items(j0, WHI);                  // (the fetch of chunk i + 3 behind items 0, 1 needs the source pixel of all three)
-          load_pairs(chunk, cs_, ssq);
-        };
-        if (SR3_PP_STRICT && late) SR3_PP_BARRIER_G();
-        if (PF) pre_T(raw0, 1);
-        SR3_PP_BARRIER_V();
-        for (int i = 0; i < nck; ++i) {
-          float* rcur = (i & 1) ? raw1 : raw0;
-          const float* rnext = (i & 1) ? raw0 : raw1;
-          const bool more = i + 1 < nck;
-          const bool stage = i + 2 < nck && !(DBG & 32);
-          const int z = i & 1;
-          tok_wait(); SR3_SB(); mfma_split(0, 0, vs); SR3_SB(); tok_done();                                   // G1
-          SR3_PP_BARRIER_G();
-          do_T(rcur, 1);                                          // V1: split b (m0) ; transform m1
-          SR3_SB();
-          if (PFS && stage) {
-            // chunk i + 2's raw items were fetched a whole iteration ago (the prologue for i == 0) and every load issued since --
-            // the U fragments of this chunk -- is consumed by G1 / G2: waiting for all of them here costs nothing
-            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
-            SR3_SB();
-            pre_S(c_begin + i + 2, z, 0, 2);
-          }
-          SR3_PP_BARRIER_V();
-          SR3_PP_CHUNK_BARRIER(true);
-          tok_wait(); SR3_SB(); mfma_split(0, 1, vs); SR3_SB(); tok_done();                                   // G2
-          SR3_PP_BARRIER_G();
-          SR3_PP_CHUNK_BARRIER(false);
-          sp3(va0, va1, vs[0], vs[1], vs[2]);                     // V2: split a (m1) ; stage items 0, 1 ; fetch chunk i + 3
-          SR3_SB();
-          if (stage) {
-            if (!PFS) {
-              __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): see above
-              SR3_SB();
-              pre_S(c_begin + i + 2, z, 0, 2);
-            }
-            store_raw(rcur, c_begin + i + 2, rz, cs_, 0, 2, ssq);
-            SR3_SB();
-            if (i + 3 < nck) dma_raw(c_begin + i + 3, z ^ 1);
-          }
-          SR3_SB();
-          if (PF) { if (more) pre_T(rnext, 0); else fetch_vb(); }
-          SR3_PP_BARRIER_V();
-          tok_wait(); SR3_SB(); mfma_split(1, 0, vs); SR3_SB(); tok_done();                                   // G3
-          if (more) load_us(c_begin + i + 1, 0);
-          SR3_PP_BARRIER_G();
-          if (more) do_T(rnext, 0);                               // V3: split b (m1) ; transform m0 of chunk i + 1
-          else { if (!PF) fetch_vb(); sp3(vb0, vb1, vs[0], vs[1], vs[2]); }
-          SR3_SB();
-          if (PFS && stage) pre_S(c_begin + i + 2, z, 2, 3);
-          SR3_PP_BARRIER_V();
-          tok_wait(); SR3_SB(); mfma_split(1, 1, vs); SR3_SB(); tok_done();                                   // G4
-          if (more) load_us(c_begin + i + 1, 1);
-          SR3_PP_BARRIER_G();
-          if (more) sp3(va0, va1, vs[0], vs[1], vs[2]);           // V4: split a (m0 of chunk i + 1) ; stage item 2
-          SR3_SB();
-          if (stage) {
-            if (!PFS) pre_S(c_begin + i + 2, z, 2, 3);
-            store_raw(rcur, c_begin + i + 2, rz, cs_, 2, 3, ssq);
-          }
-          SR3_SB();
-          if (PF && more) pre_T(rnext, 1);
-          SR3_PP_BARRIER_V();
-        }
-        if (SR3_PP_STRICT && !late) SR3_PP_BARRIER_G();
-#undef SR3_PP_BARRIER_V
-#undef SR3_PP_BARRIER_G
-#undef SR3_PP_CHUNK_BARRIER
-      }
+#include "conv3x3_wino_pp.inc"
 #else
       {
         f32x4 da[3], db[3];
