@@ -953,6 +953,7 @@ int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out) {
   if (!desc || !out) { set_error("null argument"); return SR3_E_BADARG; }
   sr3_plan* P = new (std::nothrow) sr3_plan();
   if (!P) { set_error("out of host memory"); return SR3_E_NOMEM; }
+  { const char* e = getenv("SR3_WGRAD_SPLIT"); if (e) P->wgrad_split = atoi(e); }      // A/B knob: default of plan option wgrad_split
 #ifdef SR3_EXPERIMENTS
   { const char* e = getenv("SR3_WINO4"); if (e) P->wino4 = atoi(e); }      // A/B knob: default of plan option wino4
 #endif
@@ -1022,6 +1023,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "winograd")) slot = &plan->winograd;
   else if (!strcmp(key, "wino_split")) slot = &plan->wino_split;
   else if (!strcmp(key, "wino_split8")) slot = &plan->wino_split8;
+  else if (!strcmp(key, "wgrad_split")) { const int prev = plan->wgrad_split; plan->wgrad_split = value; return prev; }   // no rebuild (the slabs are sized for both)
   else if (!strcmp(key, "attn_split")) { const int prev = plan->attn_split; plan->attn_split = value; return prev; }   // no rebuild
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;

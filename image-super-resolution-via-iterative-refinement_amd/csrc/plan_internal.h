@@ -109,6 +109,7 @@ struct sr3_plan {
                              // above the fp32-MFMA instantiation's on every layer shape, 2000-step drift) where that exists: the
                              // one-image tile of the inference plan.  0: the exact-fp32 MFMA instantiation everywhere
   int wino_split8 = 1;       // ... and the four-image tile of the 8x8 maps too (round 5; no dropout form: the training forward keeps fp32)
+  int wgrad_split = 1;       // training: weight gradients of the layers with > 64 channels either side on the split kernel (wgrad.hip; round 5)
   int attn_split = 1;        // SelfAttention's two contractions on the 3 x bf16 split instantiation of k_attention_v2 (round 5)
   int gemm_tile = 0;         // A/B knob: force this im2col tile (1-4) on every conv of that kernel; 0 = conv_pick's choice
   int gemm_split = 1;        // the im2col kernel (1x1 and stride-2 convs) on its 3 x bf16 split instantiations (conv_igemm.hip)

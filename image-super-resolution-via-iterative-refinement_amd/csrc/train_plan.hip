@@ -62,6 +62,7 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
 
 int wgrad_call(const TrainCtx& X, ConvParams c, const float* dy, float* dw) {
   WgradParams wp;
+  c.wgrad_split = X.P->wgrad_split;
   wp.c = c;
   wp.dy = dy;
   wp.dw = dw;

@@ -8,6 +8,8 @@
 // fragments with conflict-free ds_read_b32 (lanes along channels).  Workgroup tile TN x TC of one
 // filter tap; pixels are walked in chunks of 32, register-prefetched and double-buffered; the pixel
 // range is split over gridDim.z and the partial slabs are summed by a deterministic reduce kernel.
+#include <algorithm>
+
 #include "sr3_common.h"
 #include "train.h"
 
@@ -144,6 +146,192 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
       }
       if (more) store(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  float* dst = slabs + (size_t)blockIdx.z * p.Cout * taps * Cin;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int c = tile_c * TC + wave_c * WC + 32 * j + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = tile_n * TN + wave_n * WN + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (n < p.Cout && c < Cin) dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_32x32x16_bf16 with 3-way split fp32 operands (round 5; plan option wgrad_split, default off until
+// its evidence is whole): six bf16 products per fp32 product, fp32 accumulation -- the arithmetic of the split conv kernels.
+// The contraction runs over PIXELS, which are the rows of both NHWC operands, while a bf16 MFMA operand wants 8 consecutive k per
+// lane: the staging step transposes.  A unit of staging = 8 consecutive pixels (one k-half of a 16-pixel k-step) x 4 channels:
+// eight 16-byte loads, per channel one split3x8 of the eight pixel values, three 16-byte LDS writes into
+//   plane[3][k-step 2][k-half 2][row][8 bf16]        (row = output channel n for dy, input channel c for the activations)
+// so that a lane's MFMA operand is ONE conflict-free ds_read_b128 (lanes along rows).  One tap per workgroup (blockIdx.y), so
+// the tap shift lives in the loader's pixel address and nothing has to be re-aligned; 3x3 stride-1 layers run here too under
+// wgrad_split (the 9-tap kernel's shared halo would need funnel-shifted fragments).  Single LDS stage,
+// the next chunk's loads in flight in registers across the MFMAs.  TN = TC = 128: one unit per thread and operand pair;
+// 64 x 64: units of 4 pixels (two threads fill one fragment with 8-byte writes).
+// ---------------------------------------------------------------------------------------------------
+template <int TN, int TC, bool ACT>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(const ConvParams p, const float* __restrict__ dy,
+                                                              float* __restrict__ slabs, int chunks_per_split, int logW,
+                                                              int logHW) {
+  constexpr int WN = TN / 2, WC = TC / 2;
+  constexpr int MI = WN / 32, NI = WC / 32;
+  constexpr int PX = (TN == 128) ? 8 : 4;                 // pixels per staging unit
+  constexpr int ROWS = TN + TC;                           // fragment rows per (k-step, k-half): dy rows then activation rows
+  extern __shared__ f32x4 smem_v[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem_v);     // [plane 3][ks 2][kh 2][ROWS][8]
+  constexpr int PLANE = 4 * ROWS * 8;                     // bf16 elements per plane
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Cin = p.C0 + p.C1;
+  const int taps = p.ksize * p.ksize;
+  const int pad = p.ksize / 2;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int Hi = p.Hs << p.ups, Wi = p.Ws << p.ups;
+  const int tiles_c = (Cin + TC - 1) / TC;
+  const int tile_n = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_n * tiles_c;
+  const int tap = blockIdx.y;
+  const int fr = tap / p.ksize, fs = tap - fr * p.ksize;
+  const int nchunks = (M + 31) / 32;
+  const int ch0 = blockIdx.z * chunks_per_split;
+  const int ch1 = min(nchunks, ch0 + chunks_per_split);
+
+  // staging unit of this thread: threads 0-127 (waves 0, 1) stage dy, threads 128-255 the activations; within an operand the unit
+  // is (channel quad uq, pixel group ug): TN = 128: 32 quads x 4 groups of 8 pixels, TN = 64: 16 quads x 8 groups of 4 pixels
+  const bool is_act = tid >= 128;
+  const int u = tid & 127;
+  constexpr int QUADS = TN / 4;                           // (TN == TC)
+  const int uq = u % QUADS, ug = u / QUADS;               // quad, pixel group (8 px: 0..3; 4 px: 0..7)
+  f32x4 rv[PX], sa[ACT ? PX : 1], sb[ACT ? PX : 1];       // (ACT: the GroupNorm pairs of the unit's pixels travel with the prefetch)
+  bool rok[PX];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](int chunk) {
+    const int n = tile_n * TN + uq * 4;
+    const int c = tile_c * TC + uq * 4;
+    const bool nv = n < p.Cout, cv = c < Cin;
+    const int ce = cv ? c : 0;
+    const bool second = ce >= p.C0;
+    const float* sp = second ? p.src1 : p.src0;
+    const int sC = second ? p.C1 : p.C0;
+    const int cs = second ? ce - p.C0 : ce;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      const int m = chunk * 32 + ug * PX + i;
+      const bool mv = m < M;
+      const int me = mv ? m : 0;
+      int b, oh, ow;
+      if (logW >= 0) {
+        b = me >> logHW;
+        const int rem = me & (HoWo - 1);
+        oh = rem >> logW; ow = rem & (p.Wo - 1);
+      } else {
+        b = me / HoWo;
+        const int rem = me - b * HoWo;
+        oh = rem / p.Wo; ow = rem - oh * p.Wo;
+      }
+      if (!is_act) {
+        rok[i] = mv && nv;
+        rv[i] = *reinterpret_cast<const f32x4*>(dy + (rok[i] ? me * p.Cout + n : 0));
+      } else {
+        const int ih = oh * p.stride + fr - pad, iw = ow * p.stride + fs - pad;
+        const bool ok = mv && cv && (unsigned)ih < (unsigned)Hi && (unsigned)iw < (unsigned)Wi;
+        rok[i] = ok;
+        const int pix = (b * p.Hs + (ih >> p.ups)) * p.Ws + (iw >> p.ups);
+        rv[i] = *reinterpret_cast<const f32x4*>(sp + (ok ? pix * sC + cs : 0));
+        if constexpr (ACT) {
+          const float* q = p.ss + (b * Cin + ce) * 2;
+          sa[i] = *reinterpret_cast<const f32x4*>(q);
+          sb[i] = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+      }
+    }
+  };
+  auto store = [&]() {
+    f32x4 v[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      v[i] = rv[i];
+      if constexpr (ACT) if (is_act) {
+        v[i].x = fmaf(v[i].x, sa[i].x, sa[i].y);
+        v[i].y = fmaf(v[i].y, sa[i].z, sa[i].w);
+        v[i].z = fmaf(v[i].z, sb[i].x, sb[i].y);
+        v[i].w = fmaf(v[i].w, sb[i].z, sb[i].w);
+        if (p.act == 2) { v[i].x = silu_w(v[i].x); v[i].y = silu_w(v[i].y); v[i].z = silu_w(v[i].z); v[i].w = silu_w(v[i].w); }
+      }
+      if (!rok[i]) v[i] = zero;
+    }
+    // k position of the unit's pixels inside the chunk: pixel index ug * PX + i = 16 ks + 8 kh + e
+    const int p0 = ug * PX;
+    const int ks = p0 >> 4, kh = (p0 >> 3) & 1, e0 = p0 & 7;          // (PX = 8: e0 = 0; PX = 4: e0 = 0 or 4)
+    const int row0 = (is_act ? TN : 0) + uq * 4;
+#pragma unroll
+    for (int chn = 0; chn < 4; ++chn) {
+      __bf16* dstp = planes + ((size_t)(ks * 2 + kh) * ROWS + row0 + chn) * 8 + e0;
+      if constexpr (PX == 8) {
+        const f32x4 lo = {v[0][chn], v[1][chn], v[2][chn], v[3][chn]}, hi = {v[4][chn], v[5][chn], v[6][chn], v[7][chn]};
+        bf16x8 h, m, l;
+        split3x8(lo, hi, h, m, l);
+        *reinterpret_cast<bf16x8*>(dstp) = h;
+        *reinterpret_cast<bf16x8*>(dstp + PLANE) = m;
+        *reinterpret_cast<bf16x8*>(dstp + 2 * PLANE) = l;
+      } else {
+        const f32x4 q4 = {v[0][chn], v[1][chn], v[2][chn], v[3][chn]};
+        bf16x4 h, m, l;
+        split3(q4, h, m, l);
+        *reinterpret_cast<bf16x4*>(dstp) = h;
+        *reinterpret_cast<bf16x4*>(dstp + PLANE) = m;
+        *reinterpret_cast<bf16x4*>(dstp + 2 * PLANE) = l;
+      }
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave_n = wave >> 1, wave_c = wave & 1;
+  const int nrow = wave_n * WN + (lane & 31);             // fragment row of this lane's dy operand (+ 32 i)
+  const int crow = TN + wave_c * WC + (lane & 31);        // ... of its activation operand (+ 32 j)
+  const int khl = lane >> 5;
+
+  if (ch0 < ch1) {
+    load(ch0);
+    store();
+    __syncthreads();
+    for (int ch = ch0; ch < ch1; ++ch) {
+      const bool more = ch + 1 < ch1;
+      if (more) load(ch + 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[MI][3], bq[NI][3];
+        const __bf16* base = planes + (size_t)(ks * 2 + khl) * ROWS * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) a[i][pl] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + (nrow + 32 * i) * 8);
+#pragma unroll
+          for (int j = 0; j < NI; ++j) bq[j][pl] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + (crow + 32 * j) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) mfma_split6(a[i], bq[j], acc[i][j]);
+      }
+      __syncthreads();                       // every fragment of this chunk is read
+      if (more) store();
       __syncthreads();
     }
   }
@@ -313,10 +501,14 @@ bool wgrad9_ok(const ConvParams& c) {
   const int rpc = 32 / Wc;
   return c.Ho % rpc == 0 && (c.Ho * c.Wo) % 32 == 0;
 }
+// plan option wgrad_split: the one-tap-per-workgroup split kernel on its 128 x 128 tile, i.e. for every layer with more than 64
+// input and output channels (3x3 layers included); the 64-channel layers keep their kernels (the 64 x 64 split tile stages as
+// many operand values per MFMA as it saves: 292 VALU instructions per 12 MFMAs)
+bool wgrad_use_split(const ConvParams& c) { return c.wgrad_split && c.Cout > 64 && c.C0 + c.C1 > 64; }
 void wgrad_geometry(const ConvParams& c, int* tn, int* tc, int* msplit, int* cps) {
   const int Cin = c.C0 + c.C1;
   const int taps = c.ksize * c.ksize;
-  if (wgrad9_ok(c)) {
+  if (wgrad9_ok(c) && !wgrad_use_split(c)) {
     *tn = 64; *tc = 64;
     const long tiles = (long)cdivw(c.Cout, 64) * cdivw(Cin, 64);
     const int nchunks = c.B * c.Ho * c.Wo / 32;
@@ -360,14 +552,38 @@ int launch_wgrad(const WgradParams& p, int msplit, int cps, hipStream_t st) {
   SR3_LAUNCH_CHECK("k_conv_wgrad");
   return SR3_OK;
 }
+template <int TN, int TC>
+int launch_wgrad_split(const WgradParams& p, int msplit, int cps, hipStream_t st) {
+  constexpr int smem = 3 * 4 * (TN + TC) * 8 * 2;         // three planes of [ks 2][kh 2][TN + TC rows][8 bf16]
+  static std::atomic<uint64_t> attr_done{0};
+  auto kern = p.c.act != 0 ? k_conv_wgrad_split<TN, TC, true> : k_conv_wgrad_split<TN, TC, false>;
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv_wgrad_split<TN, TC, true>), smem, attr_done)) return rc;
+  static std::atomic<uint64_t> attr_done2{0};
+  if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv_wgrad_split<TN, TC, false>), smem, attr_done2)) return rc;
+  const int Cin = p.c.C0 + p.c.C1;
+  const int taps = p.c.ksize * p.c.ksize;
+  dim3 grid(cdivw(p.c.Cout, TN) * cdivw(Cin, TC), taps, msplit);
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  int logW = lg(p.c.Wo), logHW = lg(p.c.Ho * p.c.Wo);
+  if (logW < 0 || logHW < 0) logW = logHW = -1;
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p.c, p.dy, msplit > 1 ? p.slabs : p.dw, cps, logW, logHW);
+  SR3_LAUNCH_CHECK("k_conv_wgrad_split");
+  return SR3_OK;
+}
 }  // namespace
 
 size_t wgrad_slab_bytes(const ConvParams& c, int* msplit_out) {
-  int tn, tc, ms, cps;
-  wgrad_geometry(c, &tn, &tc, &ms, &cps);
-  if (msplit_out) *msplit_out = ms;
-  if (ms <= 1) return 0;
-  return (size_t)ms * c.Cout * c.ksize * c.ksize * (c.C0 + c.C1) * sizeof(float);
+  // the slab size covers BOTH geometries (the plan sizes its scratch before it knows the option), msplit is the one the launch uses
+  size_t bytes = 0;
+  ConvParams v = c;
+  for (int mode = 0; mode < 2; ++mode) {
+    v.wgrad_split = mode;
+    int tn, tc, ms, cps;
+    wgrad_geometry(v, &tn, &tc, &ms, &cps);
+    if (mode == (c.wgrad_split ? 1 : 0) && msplit_out) *msplit_out = ms;
+    if (ms > 1) bytes = std::max(bytes, (size_t)ms * c.Cout * c.ksize * c.ksize * (c.C0 + c.C1) * sizeof(float));
+  }
+  return bytes;
 }
 
 int conv_wgrad(const WgradParams& p, hipStream_t st) {
@@ -384,7 +600,9 @@ int conv_wgrad(const WgradParams& p, hipStream_t st) {
   if (ms != p.msplit) { set_error("wgrad: msplit mismatch (%d vs %d)", ms, p.msplit); return SR3_E_BADARG; }
   if (ms > 1 && !p.slabs) { set_error("wgrad: slabs required"); return SR3_E_BADARG; }
   int rc;
-  if (wgrad9_ok(c)) {
+  if (wgrad_use_split(c)) {
+    rc = launch_wgrad_split<128, 128>(p, ms, cps, st);
+  } else if (wgrad9_ok(c)) {
     constexpr int smem9 = 2 * (32 + 102) * 68 * 4;
     static std::atomic<uint64_t> attr9_done{0};
     if (int rc9 = ensure_max_lds(reinterpret_cast<const void*>(k_conv_wgrad9), smem9, attr9_done)) return rc9;

@@ -112,6 +112,9 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   a training forward's dropout convs on 8x8 maps keep the fp32 MFMA).
  * gemm_wpre (default 0): the im2col split tiles read their weights pre-split from the derived buffer (tiles 18-21) instead of
  *   splitting them while staging; measured slower in both layouts tried (profiles/r05b_*), kept as an A/B knob.
+ * wgrad_split (default 1, round 5; training): weight gradients of every layer with more than 64 input and output channels on
+ *   v_mfma_f32_32x32x16_bf16 with 3-way split operands (wgrad.hip), gated by the batch-64 gradient tests against float64 autograd;
+ *   0: the fp32-MFMA weight-gradient kernels.  No rebuild of the plan.
  * attn_split (default 1, round 5): SelfAttention's two contractions (Q K^T, P V) on the 3 x bf16 split instantiation of the
  *   staging-free kernel, gated against float64 like the convolutions; 0: v_mfma_f32_32x32x2_f32.  No rebuild of the plan.
  * wino4 (default 0, experimental; needs a library built with -DSR3_EXPERIMENTS, refused otherwise): wino_split convolutions on the
