@@ -2,7 +2,7 @@
 # Round evidence, pass 1 of 2 (through gpurun): everything that must exist under profiles/ BEFORE the final bench line is taken,
 # because bench.py reads the counter summaries of the round from there -- smoke, rocprofv3 kernel statistics of the sampling leg,
 # the counter passes (FETCH_SIZE, WRITE_SIZE, SQ set; default and exact-fp32 plans), the per-launch table, kernel statistics of a
-# training step and of stock PyTorch-ROCm.  Pass 2 = tools/final_bench.sh <tag> (+ the test suite).
+# training step and of stock PyTorch-ROCm.  Pass 2 = tools/evidence_pass2.sh <tag> (bench line, 1-rank launcher lines, the -m gpu suite).
 #   bash tools/evidence_pass1.sh r05
 set -u
 TAG=${1:-r05}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The three counter passes of tools/round_profile.sh on their own (FETCH_SIZE, WRITE_SIZE, SQ set; each its own run, --kernel-trace only):
+# The three counter passes of a round (tools/evidence_pass1.sh, tools/round_profile.sh) on their own (FETCH_SIZE, WRITE_SIZE, SQ set; each its own run, --kernel-trace only):
 #   bash tools/pmc_passes.sh <tag> [extra bench.py flags, e.g. --exact-fp32]      (through gpurun; writes gpurun_out/<tag>/{fetch,write,sq} + the summaries of pmc_traffic.py / pmc_sq.py)
 set -u
 TAG=${1:-r04}
