@@ -320,3 +320,27 @@ def test_dropout_threshold_matches_the_oracle_mask():
         assert t == int(p * 4294967296.0), (p, t)
         assert np.float32(s.value) == np.float32(1.0 / (1.0 - p)), (p, s.value)
     assert lib.sr3_dropout_threshold(C.c_float(0.0), None) == 0
+
+
+def test_round5_plan_options_no_gpu():
+    """The plan options added in round 5 are accepted, return the previous value, and the structural one changes the launch
+    list as documented (include/sr3_mi355x.h): wino_split8 moves the four-image 8x8 tile between tiles 12 and 11; attn_split /
+    wgrad_split are run-time switches that leave the list alone; gemm_wpre moves the im2col split tiles to 18-21."""
+    from sr3_hip import engine as E
+    p = E.Plan('sr3', 6, 3, 64, 32, [1, 2, 4, 8, 8], [16], 2, 128)
+    ops = p.op_list(16)
+    w8 = [o for o in ops if o['kind'] == 50 and o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] == 8]
+    assert len(w8) == 14 and all(o['tile_cfg'] == 12 and o['ksplit'] >= 2 for o in w8)
+    assert p.set_option('wino_split8', 0) == 1
+    ops0 = p.op_list(16)
+    assert [o['tile_cfg'] for o in ops0 if o['kind'] == 50 and o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] == 8] == [11] * 14
+    assert all(a['tile_cfg'] == b['tile_cfg'] for a, b in zip(ops, ops0) if not (a['kind'] == 50 and a['h_out'] == 8 and a['ksize'] == 3))
+    assert p.set_option('wino_split8', 1) == 0 and p.op_list(16) == ops
+    for key in ('attn_split', 'wgrad_split'):
+        assert p.set_option(key, 0) == 1 and p.op_list(16) == ops
+        assert p.set_option(key, 1) == 0
+    assert p.set_option('gemm_wpre', 1) == 0
+    assert sorted(set(o['tile_cfg'] for o in p.op_list(16) if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [20]
+    assert p.set_option('gemm_wpre', 0) == 1 and p.op_list(16) == ops
+    with pytest.raises(Exception):
+        p.set_option('no_such_option', 1)
