@@ -519,6 +519,9 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'unit': 'images/s', 'steps_per_s': 1e3 / ms, 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
             'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': c['unet']['dropout'],
             'optimizer': 'Adam lr %g' % c['lr'],
+            'arithmetic': 'fp32 tensors and accumulation; forward convs, data gradients and (layers with > 64 channels either side) weight '
+                          'gradients as six bf16 MFMA products of 3-way split fp32 operands (plan options wino_split / gemm_split / '
+                          'wgrad_split, default on; gradients gated against float64 autograd in tests/)',
             'parallelism': 'dp%d, tail-first 32 MB gradient buckets all-reduced (RCCL) as the backward produces them' % world,
             'tflops_at_3x_forward': fl / (ms * 1e-3) / 1e12,
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix'],
