@@ -11,11 +11,11 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 if [ "${1:-}" = "--clean" ]; then rm -rf "$BUILD"; shift; fi
 mkdir -p "$BUILD"
-SRCS="conv_igemm conv3x3_halo conv3x3_wino conv3x3_wino4 small_kernels attention plan train_kernels train_small wgrad attention_bwd train_plan io_metrics resize"
+SRCS="conv_igemm conv3x3_halo conv3x3_wino conv3x3_wino2 small_kernels attention plan train_kernels train_small wgrad attention_bwd train_plan io_metrics resize"
 pids=()
 for f in $SRCS; do
   o=$BUILD/$f.o
-  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ sr3_common.h -nt $o ] || [ train.h -nt $o ] || [ plan_internal.h -nt $o ] || [ conv3x3_wino_pp.inc -nt $o ] || [ ../../include/sr3_mi355x.h -nt $o ] || [ ../../include/sr3_io_mi355x.h -nt $o ]; then
+  if [ ! -f $o ] || [ $f.hip -nt $o ] || [ sr3_common.h -nt $o ] || [ train.h -nt $o ] || [ plan_internal.h -nt $o ] || [ ../../include/sr3_mi355x.h -nt $o ] || [ ../../include/sr3_io_mi355x.h -nt $o ]; then
     $HIPCC $FLAGS "$@" -c $f.hip -o $o &
     pids+=($!)
   fi

@@ -42,22 +42,6 @@
 #ifndef SR3_WINO_PRE
 #define SR3_WINO_PRE 0
 #endif
-#ifndef SR3_WINO_PARKB
-#define SR3_WINO_PARKB 1     // ping-pong loop: position b's transformed values wait in LDS between transform and split (A/B)
-#endif
-#ifndef SR3_PP_TOKEN
-#define SR3_PP_TOKEN 0       // ping-pong loop, relaxed form: MFMA clusters of a SIMD's two waves handed off through LDS counters (A/B)
-#endif
-#ifndef SR3_PP_STRICT
-#define SR3_PP_STRICT 0      // ping-pong loop: 1 = a workgroup barrier behind every cluster, 0 = one per chunk, staggered (A/B)
-#endif
-#ifndef SR3_PP_PREFETCH
-#define SR3_PP_PREFETCH 0    // ping-pong loop: LDS reads of a VALU cluster issued ahead of the MFMA cluster in front of it (A/B)
-#endif
-#ifndef SR3_WINO_PP
-#define SR3_WINO_PP 0        // SPLIT main loop: 0 = round 4's one-barrier-per-chunk loop; 1 = the clustered ("ping-pong") schedule of round 5, an
-                             // A/B build: parity-green, measured equal (relaxed) or slower (strict / hand-off / prefetch) -- DESIGN.md section 3.1e
-#endif
 #ifdef SR3_SPLIT_NOSB
 #define SR3_SB() do {} while (0)
 #else
@@ -102,8 +86,7 @@ constexpr int W_CST_F = 64 + W_MAX_CK * 2 * WCK;      // per-tile constants: bia
                                                       // during the epilogue
 static_assert(2 * W_RAW_F <= W_EXCH_F && W_RAW_F == WGeo<false>::RAW_F && 2 * WGeo<true>::RAW_F <= W_EXCH_F,
               "the raw tiles live inside the exchange block's footprint");
-constexpr int W_TOK_F = W_EXCH_F + 2 * W_CST_F;        // 8 hand-off counters of the SPLIT loop, behind the constants (the epilogue's exchange block must not touch them)
-constexpr int W_SMEM = (W_TOK_F + 8) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
+constexpr int W_SMEM = (W_EXCH_F + 2 * W_CST_F) * 4;   // 143,360 + 16,896 of the CU's 163,840 bytes
 static_assert(W_SMEM <= 163840, "LDS");
 
 // x * sigmoid(x) with the hardware exp2 (v_exp_f32 on x * log2 e) and the hardware reciprocal: ~1e-7 relative error on silu,
@@ -342,7 +325,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // and re-read (three 8-byte reads) right before every staging step of the loop; the next tile's values are computed into the
   // registers again in the epilogue
   int* ptab = reinterpret_cast<int*>(smem + 2 * GE::RAW_F);       // [item][thread] of (hinfo, hpix)
-  static_assert(!SPLIT || NB4 || 2 * GE::RAW_F + 2 * WHI * WNT + (2 * WHI + 2) * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation");
+  static_assert(!SPLIT || 2 * GE::RAW_F + 2 * WHI * WNT + 3 * WNT * 4 <= W_EXCH_F, "LDS tables of the SPLIT instantiation: raw tiles, parked staging items, position b's parked planes");
   auto hinfo = [&](int j) { return hinfo_r[j]; };
   auto pixel_of = [&](int j) {                    // source pixel of staging item j of the current tile (-1: zero padding)
     const int hj = hinfo_r[j];
@@ -399,36 +382,6 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
       const int hp_ = hpx(j);
       const int off = hp_ >= 0 ? hp_ * sC + cs : 0;
       r[j] = *reinterpret_cast<const f32x4*>(sp_ + off);
-    }
-  };
-  // SPLIT, ping-pong loop: the raw loads of the main loop land in LDS instead of registers (global_load_lds_dwordx4: lane l of a
-  // wave writes 16 bytes at M0 + 16 l) -- zone[item][thread], i.e. every thread later reads back exactly what its own lane
-  // fetched, so the only synchronisation is the issuing wave's vmcnt.  The compiler does not order a later ds_read behind the
-  // transfer (checked on this toolchain), so the consumer waits on an explicit vmcnt; twelve registers fewer across the loop,
-  // where the staging loads otherwise spill (a spill right behind a global load waits for it at once).
-  f32x4* zone = reinterpret_cast<f32x4*>(ptab + 2 * WHI * WNT);       // [item][thread], behind the parked staging items
-  auto dma_raw = [&](int chunk, int z) {        // all items of `chunk` into zone parity z
-    const int c = chunk * WCK + kq * 4;
-    const int ce = c < Cin ? c : 0;
-    const bool second = ce >= p.C0;
-    const float* sp_ = second ? p.src1 : p.src0;
-    const int sC = second ? p.C1 : p.C0;
-    const int cs = second ? ce - p.C0 : ce;
-#pragma unroll
-    for (int j = 0; j < WHI; ++j) {
-      const int hp_ = hpx(j);
-      const int off = hp_ >= 0 ? hp_ * sC + cs : 0;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp_ + off),
-                                       (__attribute__((address_space(3))) void*)(zone + (z * WHI + j) * WNT + wave * 64), 16, 0, 0);
-    }
-  };
-  [[maybe_unused]] auto zone_read = [&](f32x4 (&r)[WHI], int z, int j0 = 0, int j1 = GE::WHI) {
-    int t_ = tid;
-    asm volatile("" : "+v"(t_));
-#pragma unroll
-    for (int j = 0; j < WHI; ++j) {
-      if (j < j0 || j >= j1) continue;
-      r[j] = zone[(z * WHI + j) * WNT + t_];
     }
   };
   // GroupNorm (scale, shift) of the tile's image for the channels of this workgroup's chunk range live in LDS (cst + 64 of the
@@ -657,9 +610,6 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
   // static priority for the second-dispatched half of the workgroup (the arbitration loser on every SIMD)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 #endif
-  [[maybe_unused]] int gseq = 0;                                      // SPLIT ping-pong loop: MFMA clusters this wave has issued (kernel lifetime)
-  if (SPLIT && SR3_WINO_PP && SR3_PP_TOKEN && tid < 8)
-    reinterpret_cast<int*>(smem + W_TOK_F)[tid] = 0;       // (the first barrier below)
   // ---- first tile: constants, raw chunks 0 and 1 ------------------------------------------------------------------
   int vtile = blockIdx.x;
   int par = 0;                                       // parity of the tile: which half of the constants block it uses
@@ -707,7 +657,7 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
     park_items();
     store_raw(raw0, c_begin, rh, cs_);
     if (nck > 1) store_raw(raw1, c_begin + 1, rh2, cs_);
-    if (SPLIT && SR3_WINO_PP) dma_raw(c2, 0); else load_raw(c2, rh);
+    load_raw(c2, rh);
     __syncthreads();
     stamp(vtile, 1);
 
@@ -743,9 +693,6 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
         }
         split3x8(lo, hi, h, m, l);
       };
-#if SR3_WINO_PP
-#include "conv3x3_wino_pp.inc"
-#else
       {
         f32x4 da[3], db[3];
         t_load(raw0, 0, 0, da, db);
@@ -852,7 +799,6 @@ __global__ __launch_bounds__(WNT, 1) void k_conv3x3_wino(const ConvParams p, con
           sp3(va0, va1, vsa[0], vsa[1], vsa[2]);
         }
       }
-#endif
     } else {
       f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
       {
@@ -1091,14 +1037,17 @@ bool wino_geometry(const ConvParams& p, WinoGeom* g) {
   if (H != (p.Hs << p.ups) || W != (p.Ws << p.ups)) return false;
   // four whole 8 x 8 images per workgroup tile (split-K only: at least two 16-channel chunks)
   const bool nb4 = H == 8 && W == 8 && p.ups == 0 && (p.B % 4) == 0 && p.C0 + p.C1 > WCK;
-  if (!nb4 && (W < 16 || (W % 16) != 0 || (H % 16) != 0)) return false;
-  g->TH = nb4 ? 8 : 16; g->TW = g->TH; g->NB = nb4 ? 4 : 1;
+  // wino_split == 2: the 8 x 16 pixel tile of conv3x3_wino2.hip (two four-wave workgroups per CU)
+  const bool w2 = p.wino_split == 2;
+  if (w2 && !wino2_fits(p)) return false;
+  if (!w2 && !nb4 && (W < 16 || (W % 16) != 0 || (H % 16) != 0)) return false;
+  g->TH = (nb4 || w2) ? 8 : 16; g->TW = nb4 ? 8 : 16; g->NB = nb4 ? 4 : 1;
   g->twt = 8; g->log_twt = 3;
-  g->tpi = nb4 ? 16 : 64; g->log_tpi = nb4 ? 4 : 6;
-  g->tiles_w = nb4 ? 1 : W / 16; g->tiles_h = nb4 ? 1 : H / 16;
+  g->tpi = nb4 ? 16 : (w2 ? 32 : 64); g->log_tpi = nb4 ? 4 : (w2 ? 5 : 6);
+  g->tiles_w = nb4 ? 1 : W / 16; g->tiles_h = nb4 ? 1 : H / g->TH;
   g->nbt = nb4 ? p.B / 4 : p.B;
-  g->HPI = nb4 ? 100 : WHP;
-  g->HP = nb4 ? 400 : WHP;
+  g->HPI = nb4 ? 100 : (w2 ? 180 : WHP);
+  g->HP = nb4 ? 400 : (w2 ? 180 : WHP);
   // tile decode of the persistent kernel: shifts when the tile grid is a power of two, a magic number for / sp_tiles
   g->log_tw = ilog2x(g->tiles_w); g->log_th = ilog2x(g->tiles_h);
   g->pow2 = ((1 << g->log_tw) == g->tiles_w && (1 << g->log_th) == g->tiles_h) ? 1 : 0;
@@ -1148,7 +1097,7 @@ int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st
   if (g.NB != 1) { set_error("conv: the Winograd ablations cover the one-image tile only"); return SR3_E_BADARG; }    \
   SR3_WINO_LAUNCH3(D, false, false)
   if (p.drop_thresh != 0 && dbg != 0) { set_error("conv: the Winograd ablations have no dropout form"); return SR3_E_BADARG; }
-  if (p.wino_split == 2 && g.NB == 1 && p.drop_thresh == 0) return conv3x3_wino4_forward(p, g, ufrag, st);
+  if (p.wino_split == 2) return conv3x3_wino2_forward(p, g, ufrag, st);
   if (p.wino_split && g.NB != 1 && p.drop_thresh != 0) {
     set_error("conv: the split-bf16 four-image Winograd tile has no dropout form");
     return SR3_E_UNSUPPORTED;

@@ -485,16 +485,17 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     }
   }
   if (ksplit == 0 && tile_cfg == 11) {
-    // Winograd kernel: one 8-wave workgroup per CU, so one full round of 256 is the target; a split keeps >= 4 chunks
-    // (64 input channels)
+    // Winograd kernel: one 8-wave workgroup per CU, so one full round of 256 is the target (512 for the four-wave workgroups of
+    // conv3x3_wino2.hip, two per CU); a split keeps >= 4 chunks (64 input channels)
     WinoGeom wg;
     if (!wino_geometry(p, &wg)) { ksplit = 1; return; }
     const long tiles = wino_workgroups(p, wg);
     const int units = wino_chunks(p);
     const int maxck = wino_max_chunks_per_split(wg);
+    const long round = p.wino_split == 2 ? 512 : 256;
     int ks = 1;
-    if (tiles < 256) {
-      ks = (int)((256 + tiles - 1) / tiles);
+    if (tiles < round) {
+      ks = (int)((round + tiles - 1) / tiles);
       const int cap = units / 4 > 1 ? units / 4 : 1;
       if (ks > cap) ks = cap;
       if (ks > 16) ks = 16;

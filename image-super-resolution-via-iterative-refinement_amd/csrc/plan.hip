@@ -396,7 +396,7 @@ struct Builder {
       // train-mode dropout included); its filters sit behind the conv's fp32 ones
       WinoGeom wg;
       if (P->wino_split && wino_geometry(c, &wg) && (wg.NB == 1 || (P->wino_split8 && !o.has_drop))) {
-        c.wino_split = (P->wino4 && !o.has_drop && wg.NB == 1) ? 2 : 1;
+        c.wino_split = (P->wino2 && !o.has_drop && wg.NB == 1) ? 2 : 1;        // (2: the 8 x 16 tile of conv3x3_wino2.hip)
         o.wino_off += wino_weight_floats(Cout, C0 + C1);
       }
     }
@@ -833,6 +833,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       {   // the data gradient of a 3x3 conv runs on the Winograd kernel where it fits: its slabs and transformed filters
         WinoGeom wg;
         if (P->winograd && r.ksize == 3 && wino_geometry(g, &wg)) {
+          g.wino_split = (P->wino_split && wg.NB == 1) ? (P->wino2 ? 2 : 1) : 0;      // (what dgrad_conv launches with: its split-K choice depends on it)
           max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 11, 0));
           max_wu = std::max(max_wu, wino_weight_floats(g.Cout, g.C0, P->wino_split && wg.NB == 1) * sizeof(float));
         }
@@ -953,9 +954,10 @@ int sr3_plan_create(const sr3_unet_desc* desc, sr3_plan** out) {
   if (!desc || !out) { set_error("null argument"); return SR3_E_BADARG; }
   sr3_plan* P = new (std::nothrow) sr3_plan();
   if (!P) { set_error("out of host memory"); return SR3_E_NOMEM; }
-  { const char* e = getenv("SR3_WGRAD_SPLIT"); if (e) P->wgrad_split = atoi(e); }      // A/B knob: default of plan option wgrad_split
 #ifdef SR3_EXPERIMENTS
-  { const char* e = getenv("SR3_WINO4"); if (e) P->wino4 = atoi(e); }      // A/B knob: default of plan option wino4
+  // A/B builds only: defaults of plan options from the environment (a release library's arithmetic does not depend on the environment)
+  { const char* e = getenv("SR3_WGRAD_SPLIT"); if (e) P->wgrad_split = atoi(e); }
+  { const char* e = getenv("SR3_WINO2"); if (e) P->wino2 = atoi(e); }
 #endif
   P->d = *desc;
   const int rc = build_structure(P);
@@ -1028,11 +1030,11 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
-  else if (!strcmp(key, "wino4")) slot = &plan->wino4;
+  else if (!strcmp(key, "wino2")) slot = &plan->wino2;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
   if (!slot) { set_error("unknown option %s", key); return SR3_E_BADARG; }
 #ifndef SR3_EXPERIMENTS
-  if ((slot == &plan->split_bf16 || slot == &plan->wino4) && value != 0) {
+  if (slot == &plan->split_bf16 && value != 0) {
     set_error("option %s selects an experiment kernel that this library was built without (csrc/build.sh -DSR3_EXPERIMENTS)", key);
     return SR3_E_UNSUPPORTED;
   }
@@ -1161,7 +1163,7 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
         {
           static const int base[13] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305, 405, 505};
           kind += base[(o.tile_cfg == 11 && o.cp.wino_split) ? 12 : o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
-          if (o.tile_cfg == 11 && o.cp.wino_split == 2) kind += 20;                         // 575: the four-wave split kernel
+          if (o.tile_cfg == 11 && o.cp.wino_split == 2) kind += 20;                         // 575: the two-workgroups-per-CU split kernel (conv3x3_wino2.hip)
           if (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) kind += 600;           // 651-654: the im2col tiles on their 3 x bf16 split instantiation
           WinoGeom wg;
           if (o.tile_cfg == 11 && wino_geometry(o.cp, &wg) && wg.NB != 1) kind += 10;      // 465: the four-image 8x8 tile
@@ -1226,7 +1228,7 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   c.Cout = Cout; c.w = w; c.bias = bias; c.ss = ss; c.act = act; c.film = film; c.film_stride = film_stride;
   c.res0 = res0; c.res1 = res1; c.RC0 = res0 ? RC0 : 0; c.RC1 = res1 ? RC1 : 0;
   c.out = out; c.ostat = out_stats; c.ksplit = 1;
-  const bool wsplit = tile_cfg == 12 || tile_cfg == 13;     // tile 11 on the 3 x bf16 split instantiation (13: its four-wave form)
+  const bool wsplit = tile_cfg == 12 || tile_cfg == 13;     // tile 11 on the 3 x bf16 split instantiation (13: the 8 x 16 tile of conv3x3_wino2.hip)
   if (wsplit) { c.wino_split = tile_cfg - 11; tile_cfg = 11; }
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }     // the im2col tiles 1-4 on their 3 x bf16 split instantiation
   if (tile_cfg >= 18 && tile_cfg <= 21) {
@@ -1350,7 +1352,7 @@ int sr3_conv_stats_slices(int B, int Hs, int Ws, int ups, int Cin, int Cout, int
   memset(&c, 0, sizeof(c));
   c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = 1; c.ksize = 3; c.Ho = Hs << ups; c.Wo = Ws << ups;
   c.Cout = Cout; c.C0 = Cin;
-  if (tile_cfg == 12 || tile_cfg == 13) tile_cfg = 11;
+  if (tile_cfg == 12 || tile_cfg == 13) { c.wino_split = tile_cfg - 11; tile_cfg = 11; }     // (13: the 8 x 16 tile, its own slice count)
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
   if (tile_cfg >= 18 && tile_cfg <= 21) { c.igemm_split = 1; tile_cfg -= 17; }
   conv_pick(c, tile_cfg, ksplit);

@@ -104,7 +104,8 @@ struct sr3_plan {
   // options
   int fuse_stats = 1, fuse_res = 1, tile_cfg = 0, ksplit = 0, keep_all = 0, split_bf16 = 0;
   int winograd = 1;          // 3x3 stride-1 convs of the inference plan on the Winograd F(2x2,3x3) kernel (conv3x3_wino.hip)
-  int wino4 = 0;             // wino_split convs on the four-wave, 512-register kernel (conv3x3_wino4.hip) where it applies
+  int wino2 = 1;             // wino_split convs of the one-image tile without dropout on the two-workgroups-per-CU kernel (conv3x3_wino2.hip,
+                             // 8 x 16 pixel tile; round 6).  0: the 8-wave kernel of conv3x3_wino.hip everywhere
   int wino_split = 1;        // ... on its 3 x bf16 split instantiation (bf16 MFMA, fp32-class results; gated by tests/: error not
                              // above the fp32-MFMA instantiation's on every layer shape, 2000-step drift) where that exists: the
                              // one-image tile of the inference plan.  0: the exact-fp32 MFMA instantiation everywhere

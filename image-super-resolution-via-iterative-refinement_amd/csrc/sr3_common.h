@@ -168,7 +168,7 @@ struct ConvParams {
   // tile_cfg 11 (Winograd): this conv's transformed filters in fragment-major order (conv3x3_wino.hip)
   const float* wino_u;
   int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI);
-                       // 2: the same filters on the four-wave kernel of conv3x3_wino4.hip (tile_cfg 13)
+                       // 2: the same filters on the two-workgroups-per-CU kernel of conv3x3_wino2.hip (tile_cfg 13; 8 x 16 pixel tile)
   int igemm_split;     // im2col kernel (tile_cfg 1-4; 1x1 and stride-2 convs): 1 = its 3 x bf16 split instantiation (tile_cfg 14-17 at the ABI)
   int wgrad_split;     // weight gradient (wgrad.hip): 1 = the one-tap-per-workgroup kernel's 3 x bf16 split instantiation for every layer
   const void* w_split; // igemm_split: the weights pre-split into bf16 planes by igemm_split_weights (tile_cfg 18-21 at the ABI; a plan
@@ -235,8 +235,10 @@ int wino_chunks(const ConvParams& p);
 size_t wino_weight_floats(int Cout, int Cin, bool split = false);
 int wino_transform_weights(const float* w_ohwi, int Cout, int Cin, float* ufrag, hipStream_t st, bool split = false);
 int conv3x3_wino_forward(const ConvParams& p, const float* ufrag, hipStream_t st);
-// the 3 x bf16 split form on four 512-register waves (conv3x3_wino4.hip; ConvParams::wino_split == 2, tile_cfg 13 at the ABI)
-int conv3x3_wino4_forward(const ConvParams& p, const WinoGeom& g, const float* ufrag, hipStream_t st);
+// the 3 x bf16 split form as two independent four-wave workgroups per CU, 8 x 16 pixel tile (conv3x3_wino2.hip; ConvParams::wino_split == 2,
+// tile_cfg 13 at the ABI; wino_geometry gives that tile's geometry when wino_split == 2)
+bool wino2_fits(const ConvParams& p);
+int conv3x3_wino2_forward(const ConvParams& p, const WinoGeom& g, const float* ufrag, hipStream_t st);
 
 // ---- small kernels ------------------------------------------------------------------------
 // partial per-(b, channel) {sum, sumsq} in double of an NHWC tensor [B, HW, C]:

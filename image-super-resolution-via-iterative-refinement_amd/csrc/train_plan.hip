@@ -48,7 +48,7 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   if (X.P->winograd && ksize == 3 && wino_geometry(c, &wg) &&
       wino_weight_floats(Cin, Cg, split && wg.NB == 1) * sizeof(float) <= X.P->t_wu_bytes) {
     float* wu = X.at<float>(X.P->t_wu_off);
-    c.wino_split = (split && wg.NB == 1) ? 1 : 0;
+    c.wino_split = (split && wg.NB == 1) ? (X.P->wino2 ? 2 : 1) : 0;      // (2: the 8 x 16 tile of conv3x3_wino2.hip)
     rc = wino_transform_weights(wt, Cin, Cg, wu, X.st, c.wino_split != 0);
     if (rc) return rc;
     c.wino_u = wu;

@@ -22,12 +22,11 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _skip_experiment_tiles(request):
-    """Cases parametrised on an experiment kernel (tile_cfg / tile 7, 8, 10 = round 1's split_bf16 halo tiles, 13 = the four-wave
-    split Winograd kernel) run only against a library built with -DSR3_EXPERIMENTS; so do tests marked `experiments`."""
+    """Cases parametrised on an experiment kernel (tile_cfg / tile 7, 8, 10 = round 1's split_bf16 halo tiles) run only against a library built with -DSR3_EXPERIMENTS; so do tests marked `experiments`."""
     cs = getattr(request.node, 'callspec', None)
     tiles = [cs.params.get(k) for k in ('tile_cfg', 'tile')] if cs else []
     marked = request.node.get_closest_marker('experiments') is not None
-    if marked or any(t in (7, 8, 10, 13) for t in tiles):
+    if marked or any(t in (7, 8, 10) for t in tiles):
         sys.path.insert(0, os.path.join(ROOT, 'tests'))
         from helpers import experiments_built
         if not experiments_built():

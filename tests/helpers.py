@@ -57,14 +57,14 @@ _EXPERIMENTS = None
 
 
 def experiments_built():
-    """True when libsr3_mi355x was built with -DSR3_EXPERIMENTS (round-1 split_bf16 halo tiles 7 / 8 / 10, the four-wave split
-    Winograd kernel = tile 13 / plan option wino4): the default build leaves them out and refuses the options that select them."""
+    """True when libsr3_mi355x was built with -DSR3_EXPERIMENTS (round-1 split_bf16 halo tiles 7 / 8 / 10): the default build
+    leaves them out and refuses the option that selects them."""
     global _EXPERIMENTS
     if _EXPERIMENTS is None:
         from sr3_hip import engine as E, lib as L
         p = E.Plan('sr3', 6, 3, 8, 4, [1, 2], [8], 1, 16)
         try:
-            p.set_option('wino4', 1)
+            p.set_option('split_bf16', 1)
             _EXPERIMENTS = True
         except L.Sr3Error as e:
             assert 'SR3_EXPERIMENTS' in str(e), str(e)
@@ -72,4 +72,4 @@ def experiments_built():
     return _EXPERIMENTS
 
 
-EXPERIMENT_TILES = (7, 8, 10, 13)
+EXPERIMENT_TILES = (7, 8, 10)

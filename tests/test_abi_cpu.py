@@ -166,10 +166,12 @@ def test_plan_launch_list_no_gpu():
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:
-        assert (o['tile_cfg'] in (11, 12)) == (o['ksize'] == 3 and o['stride'] == 1), o
-        # default plan option wino_split = 1: the one-image tile (maps >= 16x16) on the kernel's 3 x bf16 split instantiation
-        # (reported as tile 12), and since round 5 (plan option wino_split8, default 1) the four-image tile of the 8x8 maps too
-        assert (o['tile_cfg'] == 12) == (o['ksize'] == 3 and o['stride'] == 1), o
+        assert (o['tile_cfg'] in (11, 12, 13)) == (o['ksize'] == 3 and o['stride'] == 1), o
+        # default plan options wino_split = 1, wino2 = 1 (round 6): maps >= 16x16 on the 3 x bf16 split arithmetic as two four-wave
+        # workgroups per CU (conv3x3_wino2.hip, reported as tile 13), and (wino_split8, round 5) the four-image tile of the 8x8 maps on
+        # the 8-wave kernel's split instantiation (tile 12)
+        assert (o['tile_cfg'] in (12, 13)) == (o['ksize'] == 3 and o['stride'] == 1), o
+        assert (o['tile_cfg'] == 13) == (o['ksize'] == 3 and o['stride'] == 1 and o['h_out'] >= 16), o
         assert not o['fused_res_conv_cin']
         if o['tile_cfg'] in (11, 12) and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
             assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
@@ -197,14 +199,20 @@ def test_plan_launch_list_no_gpu():
     eops = p.op_list(16)
     assert len(eops) == len(wops)
     for a, b in zip(wops, eops):
-        assert b['tile_cfg'] == (11 if a['tile_cfg'] == 12 else a['tile_cfg']) and a['ksplit'] == b['ksplit'] and a['flops'] == b['flops']
+        assert b['tile_cfg'] == (11 if a['tile_cfg'] in (12, 13) else a['tile_cfg']) and a['flops'] == b['flops']
+        assert a['ksplit'] == b['ksplit'] or a['tile_cfg'] == 13      # (the 8 x 16 tile fills 512 workgroup slots: its own split-K choice)
     # the derived buffer holds both forms of every filter under wino_split (fp32 + 1.5x that for the three bf16 planes)
     assert abs((nbytes_both - nbytes_wsplit) / (int(p.lib.sr3_plan_derived_bytes(p.handle)) - nbytes_wsplit) - 2.5) < 1e-6
     p.set_option('wino_split', 1)
+    p.set_option('wino2', 0)                              # the 8-wave kernel everywhere (round 5's plan): tile 12
+    for a, b in zip(wops, p.op_list(16)):
+        assert b['tile_cfg'] == (12 if a['tile_cfg'] == 13 else a['tile_cfg']) and a['flops'] == b['flops']
+    p.set_option('wino2', 1)
+    assert p.op_list(16) == wops
     # a batch that is not a multiple of 4 keeps the direct halo kernel on the 8x8 maps
     for o in p.op_list(3):
         if o['kind'] == 50 and o['ksize'] == 3 and o['stride'] == 1:
-            assert (o['tile_cfg'] == 12) == (o['h_out'] >= 16) and o['tile_cfg'] != 11, o
+            assert (o['tile_cfg'] == 13) == (o['h_out'] >= 16) and o['tile_cfg'] not in (11, 12), o
     assert sum(1 for o in wconvs if o['ksize'] == 1) == 12 + 18
     assert abs(sum(o['flops'] for o in wops) / 16 / 1e9 - 92.18) < 0.05       # algorithmic FLOPs do not change
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) > 0

@@ -215,7 +215,7 @@ STRESS_CASES = [
 ]
 
 
-@pytest.mark.parametrize('tile', [11, 12, 13], ids=['fp32', 'split', 'split4w'])
+@pytest.mark.parametrize('tile', [11, 12, 13], ids=['fp32', 'split', 'split2wg'])
 @pytest.mark.parametrize('ksplit', [0, 1])
 @pytest.mark.parametrize('case', STRESS_CASES, ids=[c[0] for c in STRESS_CASES])
 def test_winograd_conv_stress_absolute_bound(case, ksplit, tile):
@@ -287,7 +287,7 @@ def test_winograd_conv_error_is_fp32_class(case, ksplit):
 SPLIT_GATE_CASES = list(WINO_CASES)          # (round 5: the four-image 8x8 tile has its split instantiation too -- tile 12 only)
 
 
-@pytest.mark.parametrize('tile', [12, 13], ids=['8wave', '4wave'])
+@pytest.mark.parametrize('tile', [12, 13], ids=['8wave', '2wg'])
 @pytest.mark.parametrize('ksplit', [0, 1, 2])
 @pytest.mark.parametrize('case', SPLIT_GATE_CASES, ids=[c[0] for c in SPLIT_GATE_CASES])
 def test_winograd_split_error_not_above_fp32_winograd(case, ksplit, tile):
@@ -296,7 +296,7 @@ def test_winograd_split_error_not_above_fp32_winograd(case, ksplit, tile):
     against float64 must not exceed the exact-fp32 Winograd kernel's (tile 11) on the same data -- rms within 5 %, max within
     25 % (the max of ~1e6 samples is a noisy statistic) -- and it must meet the same stated tolerance."""
     if case[4] < 16 and tile == 13:
-        pytest.skip('the four-wave kernel covers the one-image tile only')
+        pytest.skip('conv3x3_wino2.hip covers the one-image tile only')
     src0, src1, w, kw = _make_case(case, seed=7)
     ref = G.conv_ref(src0, src1, w, **kw)
     try:
