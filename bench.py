@@ -681,13 +681,13 @@ def time_replays(st, steps, warmup, T, dist, dev):
     return elapsed
 
 
-def other_config_leg(cfg_name, dev, steps=50, warmup=3, T=2000):
+def other_config_leg(cfg_name, dev, steps=50, warmup=3, T=2000, batch=None):
     """A bounded run of another BASELINE.json configuration (configs[3] SR3 64->512 at batch 4, configs[4] DDPM-128 at batch 32)
     for the driver's record: graph-replayed reverse steps, the parity of that graph against the CPU oracle, and the dominant
     kernel's executed-MFMA fraction.  Rank 0, N = 1 only; not part of `value`."""
     import torch
     cfg = CONFIGS[cfg_name]
-    B = cfg['batch']
+    B = batch or cfg['batch']
     netG, st = build_sampler(cfg_name, B, dev, 0)
     elapsed = time_replays(st, steps, warmup, T, None, dev)
     ms = elapsed / steps * 1e3
@@ -919,6 +919,15 @@ def main():
             except Exception as e:
                 rec['other_configs'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+        # the batch the reference's own infer.py runs (validation loader batch_size = 1, data/__init__.py:18; one 2000-step chain per
+        # image, infer.py:67-71): the launch-bound end of the same graph
+        try:
+            rec['other_configs']['sr3_16_128_b1'] = other_config_leg('sr3_16_128', dev, batch=1)
+            rec['other_configs']['sr3_16_128_b1']['note'] = ('batch 1 = what the reference infer.py feeds per call; sr3_hip.dist.ValWave batches '
+                                                             'consecutive validation items into one chain batch instead (INTEGRATION.md)')
+        except Exception as e:
+            rec['other_configs']['sr3_16_128_b1'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
         # BASELINE.json configs[4] as a TRAINING workload (DDPM-128, batch 32 / GPU, dropout 0.2): a bounded leg of 5 steps
         try:
             rec['other_configs']['ddpm_128_train'] = train_leg('ddpm_128', None, 1, 0, dev, CONFIGS['ddpm_128']['train_batch'], 5, 2)

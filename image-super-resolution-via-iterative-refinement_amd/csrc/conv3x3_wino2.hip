@@ -253,8 +253,15 @@ __global__ __launch_bounds__(VNT, 2) void k_conv3x3_wino2(const ConvParams p, co
     a[3] = *reinterpret_cast<const f32x4*>(rawbuf + (rb < 2 ? offb01 : offb23) + ((rb & 1) * VROW + kk * 8));
   };
   auto comb = [&](int i, const f32x4 (&a)[4]) {
-    const f32x4 t1 = a[0] + a[1] * sb, t2 = a[2] + a[3] * sb;
-    return (i == 1) ? t1 + t2 : t1 - t2;
+    // component by component (and the file is compiled with -fno-slp-vectorize): plain v_fma_f32 / v_sub_f32, which issue beside an
+    // MFMA; the packed forms (v_pk_fma_f32) the vector expression compiles to do not (profiles/r05a_mfma_fillers.txt)
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t1 = __builtin_fmaf(a[1][e], sb, a[0][e]), t2 = __builtin_fmaf(a[3][e], sb, a[2][e]);
+      r[e] = (i == 1) ? t1 + t2 : t1 - t2;
+    }
+    return r;
   };
   auto sp3 = [&](const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
     if (DBG & 128) {           // ablation: one conversion per value, no residuals
@@ -304,18 +311,22 @@ __global__ __launch_bounds__(VNT, 2) void k_conv3x3_wino2(const ConvParams p, co
   };
   // MFMA group of position i (U in `slot`) with the operand of the NEXT group -- position ni of the raw tile nbuf -- built inside it
   f32x4 ta[4], tlo = {0.f, 0.f, 0.f, 0.f};
-  auto group_pre = [&](const float* nbuf, int ni) { rd4(nbuf, ni, 0, ta); };
+  // (DBG & 256, timing only: the operands of the odd positions are not built -- what a V build shared by two groups would cost)
+  auto group_pre = [&](const float* nbuf, int ni) { if ((DBG & 256) && (ni & 1)) return; rd4(nbuf, ni, 0, ta); };
   auto group_run = [&](int i, int slot, const float* nbuf, int ni) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(i, slot, 0);
     __builtin_amdgcn_sched_barrier(0);
-    tlo = comb(ni, ta);
-    rd4(nbuf, ni, 1, ta);
+    if (!((DBG & 256) && (ni & 1))) {
+      tlo = comb(ni, ta);
+      rd4(nbuf, ni, 1, ta);
+    }
     __builtin_amdgcn_sched_barrier(0);
     mfma_half(i, slot, 1);
     __builtin_amdgcn_sched_barrier(0);
   };
   auto group_post = [&](int ni) {                    // ... and its 3-way split, once the group's MFMAs have read the old operand
+    if ((DBG & 256) && (ni & 1)) return;
     const f32x4 thi = comb(ni, ta);
     sp3(tlo, thi, vs[0], vs[1], vs[2]);
   };
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(VNT, 2) void k_conv3x3_wino2(const ConvParams p, co
       load_us(cn, 0, 0);
       group_post(3);
       __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
+      if (!(DBG & 512)) __syncthreads();             // (DBG & 512, timing only: no barrier in the loop)
       if (i + 2 < nck && !(DBG & 32)) {
         fetch_items();
         store_raw(rcur, c_begin + i + 2, rh, cs_);
@@ -562,11 +573,18 @@ int conv3x3_wino2_forward(const ConvParams& p, const WinoGeom& g, const float* u
   const long ntiles = wino_workgroups(p, g);
   dim3 grid((unsigned)std::min<long>(ntiles, 2L * (n_cu > 0 ? n_cu : 256)), p.ksplit);       // persistent: two workgroups per CU
   static const int dbg = [] { const char* e = getenv("SR3_WINO_DBG"); return e ? atoi(e) : 0; }();
+#ifdef SR3_WINO_ABLATIONS
+  // tooling build only: SR3_W2_ONE_PER_CU=1 asks for more LDS than two workgroups can share, i.e. ONE workgroup per CU -- how much of
+  // the kernel's time the second, independent workgroup hides
+  static const int lds_bytes = [] { const char* e = getenv("SR3_W2_ONE_PER_CU"); return (e && e[0] == '1') ? 100 * 1024 : V_SMEM; }();
+#else
+  constexpr int lds_bytes = V_SMEM;
+#endif
 #define SR3_W2_LAUNCH(D)                                                                                              \
   {                                                                                                                   \
     static std::atomic<uint64_t> done{0};                                                                             \
-    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino2<D>), V_SMEM, done)) return rc;          \
-    hipLaunchKernelGGL((k_conv3x3_wino2<D>), grid, dim3(VNT), V_SMEM, st, p, g, reinterpret_cast<const __bf16*>(ufrag)); \
+    if (int rc = ensure_max_lds(reinterpret_cast<const void*>(k_conv3x3_wino2<D>), 100 * 1024, done)) return rc;      \
+    hipLaunchKernelGGL((k_conv3x3_wino2<D>), grid, dim3(VNT), lds_bytes, st, p, g, reinterpret_cast<const __bf16*>(ufrag)); \
   }
   switch (dbg) {
     case 0: SR3_W2_LAUNCH(0) break;
@@ -579,6 +597,10 @@ int conv3x3_wino2_forward(const ConvParams& p, const WinoGeom& g, const float* u
     case 128: SR3_W2_LAUNCH(128) break;
     case 180: SR3_W2_LAUNCH(180) break;        // 4 + 16 + 32 + 128: the bare MFMA loop + prologue / epilogue
     case 181: SR3_W2_LAUNCH(181) break;        // ... without the MFMAs: prologue / epilogue only
+    case 256: SR3_W2_LAUNCH(256) break;        // operands of the odd positions not built (timing only)
+    case 288: SR3_W2_LAUNCH(288) break;        // ... and no staging in the loop
+    case 512: SR3_W2_LAUNCH(512) break;        // no workgroup barrier in the loop (timing only)
+    case 544: SR3_W2_LAUNCH(544) break;        // ... and no staging
 #endif
     default: set_error("conv: SR3_WINO_DBG=%d is not built for the two-workgroup Winograd kernel", dbg); return SR3_E_BADARG;
   }

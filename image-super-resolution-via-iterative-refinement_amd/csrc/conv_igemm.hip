@@ -39,18 +39,21 @@ __device__ __forceinline__ float silu_f(float v) {
   return SR3_SILU(v);
 }
 
-// SPLIT: 0 = fp32 MFMA, 1 = 3 x bf16 split with both operands split while staged, 2 = the same with the WEIGHTS pre-split
-// (ConvParams::w_split: three bf16 quads per weight quad, written once per weight change by igemm_split_weights -- a plan keeps
-// them in its derived buffer): every workgroup then splits only its activation rows, half of the split's VALU work
+// SPLIT: 0 = fp32 MFMA, 1 = 3 x bf16 split with both operands split while staged, 2 = the same with the WEIGHTS pre-split AND laid out
+// as the MFMA's B fragments (ConvParams::w_split, written once per weight change by igemm_split_weights -- a plan keeps them in its
+// derived buffer): a wave reads its B fragments straight from global memory, one coalesced 1 KB load per (n block, K = 16 step,
+// plane), one k-step ahead in registers -- the weights never pass through LDS, and a workgroup stages and splits only its
+// activation rows: half of the staging VALU work, half of the LDS stage (round 6; round 5's [plane][quad] layout still went
+// through the LDS staging with three loads per quad and lost, profiles/r05c_*)
 template <int BM, int BN, int TAPS, int SPLITM>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   constexpr bool SPLIT = SPLITM != 0, WPRE = SPLITM == 2;
   constexpr int BK = 32, LDK = 36, LDB = 32;
-  constexpr int NST = (SPLIT && BM + BN > 192) ? 1 : 2;      // LDS stages (single-stage on the 64x64 split tile too: 7.988 vs 7.985 ms per step, no gain)
+  constexpr int NST = (SPLIT && !WPRE && BM + BN > 192) ? 1 : 2;      // LDS stages (single-stage on the 64x64 split tile too: 7.988 vs 7.985 ms per step, no gain)
   constexpr int AR = BM / 32, BR = BN / 32;  // loader rows per thread
   constexpr int WM = BM / 2, WN = BN / 2;    // wave tile, 2x2 waves
   constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int STAGE = SPLIT ? (BM + BN) * LDB * 3 / 2 : (BM + BN) * LDK;     // floats per stage
+  constexpr int STAGE = SPLIT ? (BM + (WPRE ? 0 : BN)) * LDB * 3 / 2 : (BM + BN) * LDK;     // floats per stage (WPRE: the A rows only)
   auto swz = [](int row, int seg) { return row * LDB + (((seg ^ (row >> 2)) & 3) << 3); };   // bf16 index of a 16-byte segment
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   // instantiations' k-steps are ~1/3 as long as the fp32 ones: with one step of prefetch they were 14-40 % slower inside the
   // forward than in isolation, profiles/r04f_gemm_split_sweep.txt)
   f32x4 ra[2][AR], rw[2][WPRE ? 1 : BR], ssa[AR], ssb[AR];       // (the GroupNorm pairs, L2-hot, stay one step ahead: one set)
-  bf16x4 rws[2][WPRE ? BR : 1][3];                               // WPRE: the three planes of a weight quad as they are stored
+  bf16x8 bfr[2][2][WPRE ? NI : 1][3];                            // WPRE: B fragments [set][K = 16 step][n block][plane], one k-step ahead
   bool aok[2][AR], wok[2][BR];
   int aoff[2][AR];          // element offset of the staged quad (dropout mask index)
   using SET0 = std::integral_constant<int, 0>;
@@ -128,19 +131,31 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
       aoff[S][i] = off;
       ra[S][i] = *reinterpret_cast<const f32x4*>(sp + off);
     }
+    if constexpr (!WPRE) {
 #pragma unroll
-    for (int j = 0; j < BR; ++j) {
-      const int n = tile_n * BN + lrow + 32 * j;
-      const bool ok = cvalid && n < p.Cout;
-      wok[S][j] = ok;
-      const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
-      if constexpr (WPRE) {
-        const size_t wq = (size_t)p.Cout * TAPS * (Cin >> 2);               // quads per plane
-        const bf16x4* q = reinterpret_cast<const bf16x4*>(p.w_split) + (size_t)(off >> 2);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rws[S][j][pl] = q[(size_t)pl * wq];
-      } else {
+      for (int j = 0; j < BR; ++j) {
+        const int n = tile_n * BN + lrow + 32 * j;
+        const bool ok = cvalid && n < p.Cout;
+        wok[S][j] = ok;
+        const int off = ok ? (n * TAPS + tap) * Cin + c : 0;
         rw[S][j] = *reinterpret_cast<const f32x4*>(p.w + off);
+      }
+    }
+  };
+  // WPRE: the B fragments of k-step `it` for this wave's n blocks: w_split[n block][it][K = 16 step 2][plane 3][lane 64][8 bf16]
+  // (igemm_split_weights; zero outside Cout / Cin, so no bounds here)
+  const int wave_n_ = (tid >> 6) & 1;
+  auto load_bfrag = [&](auto set_tag, int it) {
+    constexpr int S = decltype(set_tag)::value;
+    if constexpr (WPRE) {
+      const int nb0 = (tile_n * BN + wave_n_ * WN) >> 5;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const bf16x8* q = reinterpret_cast<const bf16x8*>(p.w_split) + ((size_t)(nb0 + j) * total + it) * (2 * 3 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) bfr[S][ks][j][pl] = q[(ks * 3 + pl) * 64];
       }
     }
   };
@@ -191,18 +206,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
         *reinterpret_cast<f32x4*>(&A[(lrow + 32 * i) * LDK + kq * 4]) = v;
       }
     }
+    if constexpr (!WPRE)
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const f32x4 v = WPRE ? zero : (wok[S][j] ? rw[S][WPRE ? 0 : j] : zero);
+      const f32x4 v = wok[S][j] ? rw[S][j] : zero;
       if constexpr (SPLIT) {
         __bf16* Bb = reinterpret_cast<__bf16*>(A) + 3 * BM * LDB;     // planes [3][BN][LDB]
         bf16x4 h, m, l;
-        if constexpr (WPRE) {
-          const bf16x4 zb = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-          h = wok[S][j] ? rws[S][j][0] : zb; m = wok[S][j] ? rws[S][j][1] : zb; l = wok[S][j] ? rws[S][j][2] : zb;
-        } else {
-          split3(v, h, m, l);
-        }
+        split3(v, h, m, l);
         const int o = swz(lrow + 32 * j, kq >> 1) + (kq & 1) * 4;
         *reinterpret_cast<bf16x4*>(&Bb[o]) = h;
         *reinterpret_cast<bf16x4*>(&Bb[BN * LDB + o]) = m;
@@ -226,7 +237,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   const int brow = wave_n * WN + (lane & 31);
   const int kh = (lane >> 5) * 4;
 
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, auto bset_tag) {
+    [[maybe_unused]] constexpr int BS = decltype(bset_tag)::value;
     const float* A = smem + stage * STAGE;
     const float* Bw = A + BM * LDK;
     if constexpr (SPLIT) {
@@ -244,9 +256,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          const int o = swz(brow + 32 * j, seg);
+          if constexpr (WPRE) {
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * BN * LDB + o]);
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = bfr[BS][ks][j][pl];
+          } else {
+            const int o = swz(brow + 32 * j, seg);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * BN * LDB + o]);
+          }
         }
         // product-major order (independent accumulators between dependent MFMAs), smallest terms first
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -282,14 +299,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvParams p) {
   const int nsteps = it1 - it0;
   auto step = [&](auto set_cur, auto set_next, int i, int cur) {
     if (i + 2 < nsteps && !(p.dbg & 6)) load_global(set_cur, it0 + i + 2);
+    load_bfrag(set_next, min(it0 + i + 1, it1 - 1));       // (unconditional: the last step re-fetches its own fragments)
     if (i + 1 < nsteps && p.act != 0) load_ss(it0 + i + 1);
-    if (!(p.dbg & 1)) compute(cur);
+    if (!(p.dbg & 1)) compute(cur, set_cur);
     if constexpr (NST == 1) __syncthreads();          // single stage: every wave has read its fragments
     if (i + 1 < nsteps && !(p.dbg & 10)) store_lds(set_next, NST == 2 ? cur ^ 1 : 0);
     __syncthreads();
   };
   if (nsteps > 0) {
     load_global(SET0{}, it0);
+    load_bfrag(SET0{}, it0);
     if (nsteps > 1) load_global(SET1{}, it0 + 1);
     if (p.act != 0) load_ss(it0);
     store_lds(SET0{}, 0);
@@ -399,27 +418,42 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
 }
 
 // ---- pre-split weights of the SPLIT instantiations (ConvParams::w_split) --------------------------------------------------------
-// out[plane 3][quad q][4] bf16 with q = (OHWI element index) / 4: three planes in the weights' own order, so each of the loader's
-// three 8-byte loads of a quad is coalesced like the fp32 load it replaces (64 contiguous bytes per 32-channel row; the first
-// layout, [quad][plane][4] = one 24-byte run per thread, made every load instruction touch 3x the lines it used and was SLOWER
-// than splitting in the kernel: 1.52 vs 1.43 ms over the 33 launches)
-__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, long nquads, __bf16* __restrict__ out) {
-  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long)gridDim.x * blockDim.x) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(w + q * 4);
-    bf16x4 h, m, l;
-    split3(v, h, m, l);
-    bf16x4* o = reinterpret_cast<bf16x4*>(out) + q;
-    o[0] = h; o[nquads] = m; o[2 * nquads] = l;
+// out[n block][it = chunk * taps + tap][K = 16 step 2][plane 3][lane 64][8 bf16]: lane l of a fragment holds W[n = 32 nb + (l & 31)]
+// [tap][c = 32 chunk + 16 ks + 8 (l >> 5) .. + 7] -- the B operand of v_mfma_f32_32x32x16_bf16 in the k order the kernel's A
+// fragments have (plain channel order inside a 32-channel k-step), zero outside Cout / Cin.  One thread per fragment lane.
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ w, int Cout, int taps, int Cin, int nchunks, long nfrag,
+                                                        __bf16* __restrict__ out) {
+  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nfrag; f += (long)gridDim.x * blockDim.x) {
+    const int l = (int)(f & 63);
+    long r = f >> 6;
+    const int ks = (int)(r & 1); r >>= 1;
+    const int it = (int)(r % ((long)nchunks * taps));
+    const int nb = (int)(r / ((long)nchunks * taps));
+    const int chunk = it / taps, tap = it - chunk * taps;
+    const int n = nb * 32 + (l & 31), c = chunk * 32 + ks * 16 + 8 * (l >> 5);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (n < Cout) {
+      const float* q = w + ((size_t)n * taps + tap) * Cin + c;
+      if (c < Cin) lo = *reinterpret_cast<const f32x4*>(q);
+      if (c + 4 < Cin) hi = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+    bf16x8 h, m, lw;
+    split3x8(lo, hi, h, m, lw);
+    bf16x8* o = reinterpret_cast<bf16x8*>(out) + (((size_t)nb * nchunks * taps + it) * 2 + ks) * (3 * 64) + l;
+    o[0] = h; o[64] = m; o[128] = lw;
   }
 }
-size_t igemm_wsplit_floats(size_t numel) { return ((numel / 4) * 6 + 3) & ~(size_t)3; }     // 24 bytes per quad, rounded to 16 bytes
-int igemm_split_weights(const float* w, size_t numel, float* out, hipStream_t st) {
-  if (numel & 3) { set_error("conv: weight count %% 4 != 0"); return SR3_E_UNSUPPORTED; }
-  const long nq = (long)(numel / 4);
-  int blocks = (int)((nq + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+size_t igemm_wsplit_floats(int Cout, int taps, int Cin) {       // 3 planes x 2 bytes per padded weight
+  return (size_t)((Cout + 31) / 32) * 32 * taps * ((Cin + 31) / 32) * 32 * 6 / 4;
+}
+int igemm_split_weights(const float* w, int Cout, int taps, int Cin, float* out, hipStream_t st) {
+  if (Cin & 3) { set_error("conv: Cin %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  const int nchunks = (Cin + 31) / 32;
+  const long nfrag = (long)((Cout + 31) / 32) * nchunks * taps * 2 * 64;
+  int blocks = (int)((nfrag + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, st, w, nq, reinterpret_cast<__bf16*>(out));
+  hipLaunchKernelGGL(k_split_weights, dim3(blocks), dim3(256), 0, st, w, Cout, taps, Cin, nchunks, nfrag, reinterpret_cast<__bf16*>(out));
   SR3_LAUNCH_CHECK("k_split_weights");
   return SR3_OK;
 }
@@ -434,7 +468,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 template <int BM, int BN, int TAPS, int SPLIT = 0>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};
-  constexpr int smem = SPLIT ? ((BM + BN > 192) ? 1 : 2) * (BM + BN) * 192 : 2 * (BM + BN) * 36 * 4;
+  constexpr int smem = SPLIT == 2 ? 2 * BM * 192 : SPLIT ? ((BM + BN > 192) ? 1 : 2) * (BM + BN) * 192 : 2 * (BM + BN) * 36 * 4;
   auto kern = k_conv_igemm<BM, BN, TAPS, SPLIT>;
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, attr_done)) return rc;
   const int M = p.B * p.Ho * p.Wo;
@@ -493,6 +527,8 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
     const int units = wino_chunks(p);
     const int maxck = wino_max_chunks_per_split(wg);
     const long round = p.wino_split == 2 ? 512 : 256;
+    // (tried in round 6: no split from half a round on for the 8 x 16 tile -- 11 reduce launches fewer, the convs 0.13-0.24 ms slower:
+    // a wash, profiles/r06_wino2_experiments.txt)
     int ks = 1;
     if (tiles < round) {
       ks = (int)((round + tiles - 1) / tiles);

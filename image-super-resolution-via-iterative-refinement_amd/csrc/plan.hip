@@ -624,19 +624,19 @@ void layout_derived(sr3_plan* P) {
   P->wsplits.clear();
   P->wsplit_of.clear();
   if (P->gemm_split && P->gemm_wpre) {
-    auto regw = [&](size_t w, size_t numel) {
-      if (numel & 3) return;
-      P->wsplits.push_back({w, numel, dcur});
+    auto regw = [&](size_t w, int Cout, int taps, int Cin) {
+      if (Cin & 3) return;
+      P->wsplits.push_back({w, Cout, taps, Cin, dcur});
       P->wsplit_of[w] = dcur;
-      dcur += igemm_wsplit_floats(numel);
+      dcur += igemm_wsplit_floats(Cout, taps, Cin);
     };
     for (auto* v : {&P->downs, &P->mid, &P->ups})
       for (auto& L : *v) {
         if (L.kind == 1) {
-          if (L.res.has_rc) regw(L.res.rc_w, (size_t)L.res.cout * L.res.cin);
-          if (L.res.attn) { regw(L.res.qkv_w, (size_t)3 * L.res.cout * L.res.cout); regw(L.res.ao_w, (size_t)L.res.cout * L.res.cout); }
+          if (L.res.has_rc) regw(L.res.rc_w, L.res.cout, 1, L.res.cin);
+          if (L.res.attn) { regw(L.res.qkv_w, 3 * L.res.cout, 1, L.res.cout); regw(L.res.ao_w, L.res.cout, 1, L.res.cout); }
         } else if (L.kind == 2 && L.cout > 64) {
-          regw(L.w, (size_t)L.cout * 9 * L.cin);
+          regw(L.w, L.cout, 9, L.cin);
         }
       }
   }
@@ -682,7 +682,7 @@ Regions infer_regions(const sr3_plan* P) {
 int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
                 const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st,
-                hipEvent_t* ev, hipEvent_t* mid, const DropCfg* drop) {
+                hipEvent_t* ev, hipEvent_t* mid, const DropCfg* drop, const StepFuse* fuse) {
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
   float* film = reinterpret_cast<float*>(ws + R.film_off);
@@ -698,6 +698,7 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         memset(&e, 0, sizeof(e));
         e.variant = d.variant; e.B = B; e.inner = d.inner_channel;
         e.level = level; e.tstep = tstep; e.level_table = level_table; e.step_dev = step_dev; e.freq = freq;
+        e.step_out = fuse ? const_cast<int*>(fuse->step_cur) : nullptr;
         e.w1 = params + P->emb_w1; e.b1 = params + P->emb_b1; e.w2 = params + P->emb_w2; e.b2 = params + P->emb_b2;
         e.wf = params + P->film_w; e.bf = params + P->film_b; e.F = P->F;
         e.temb = reinterpret_cast<float*>(ws + R.temb_off); e.film = film;
@@ -774,7 +775,7 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         break;
       case OP_CONV_OUT:
         rc = conv_out_nchw(reinterpret_cast<const float*>(ws + o.a), reinterpret_cast<const float*>(ws + R.ss_off + o.ss_rel),
-                           B, o.i2, o.i2, o.i0, params + o.p0, params + o.p1, o.i1, eps_out, st);
+                           B, o.i2, o.i2, o.i0, params + o.p0, params + o.p1, o.i1, eps_out, st, fuse);
         break;
     }
     if (rc) return rc;
@@ -1090,7 +1091,7 @@ int sr3_plan_prepare_derived(sr3_plan* plan, const float* params, void* stream) 
     }
   }
   for (const auto& d : plan->wsplits) {
-    const int rc = igemm_split_weights(params + d.w, d.numel, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
+    const int rc = igemm_split_weights(params + d.w, d.Cout, d.taps, d.Cin, plan->derived_ptr + d.off, static_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
   plan->derived_from = params;
@@ -1122,6 +1123,32 @@ int sr3_unet_forward(sr3_plan* plan, const float* x_nchw, const float* cond_nchw
   return run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, noise_level, timestep, freq, level_table,
                      step_dev, params, static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream),
                      nullptr, nullptr);
+}
+
+// One whole reverse step (include/sr3_mi355x.h): the forward above with the p_sample update and the counter decrement inside the
+// output conv's kernel -- two graph nodes fewer per step than sr3_unet_forward + sr3_p_sample_step + sr3_step_decrement.
+int sr3_reverse_step(sr3_plan* plan, float* x_nchw, const float* cond_nchw, int cond_channels, const float* freq,
+                     const float* level_table, int* step2_dev, const float* params, void* workspace, size_t workspace_bytes,
+                     const float* z_nchw, const float* ta, const float* tb, const float* tc1, const float* tc2, const float* tsig,
+                     int clip_denoised, float* eps_out_nchw, int batch, void* stream) {
+  if (!plan || !x_nchw || !params || !workspace || !freq || !step2_dev || !ta || !tb || !tc1 || !tc2 || !tsig) { set_error("null argument"); return SR3_E_BADARG; }
+  if (!cond_nchw) cond_channels = 0;
+  const int rc = build_forward(plan, batch, cond_channels);
+  if (rc) return rc;
+  if (workspace_bytes < plan->ws_bytes) { set_error("workspace too small: %zu < %zu", workspace_bytes, plan->ws_bytes); return SR3_E_NOMEM; }
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)params & 15) || ((uintptr_t)x_nchw & 15) || ((uintptr_t)eps_out_nchw & 15) || ((uintptr_t)z_nchw & 15)) {
+    set_error("misaligned pointer (workspace 256 B, tensors 16 B)");
+    return SR3_E_ALIGN;
+  }
+  if (plan->d.variant == SR3_VARIANT_SR3 && !level_table) { set_error("SR3 variant needs level_table"); return SR3_E_BADARG; }
+  StepFuse f;
+  f.x = x_nchw; f.z = z_nchw; f.tb = StepTables{ta, tb, tc1, tc2, tsig};
+  f.step_cur = step2_dev; f.step_next = step2_dev + 1; f.clip = clip_denoised;
+  // the embedding kernel reads t from slot 1 and copies it to slot 0; the tail reads slot 0 and writes t - 1 to slot 1: no kernel
+  // both reads and writes a slot, so no launch of the step races with another block of itself
+  return run_forward(plan, infer_regions(plan), x_nchw, cond_nchw, cond_channels, nullptr, nullptr, freq, level_table,
+                     step2_dev + 1, params, static_cast<char*>(workspace), eps_out_nchw, batch, static_cast<hipStream_t>(stream),
+                     nullptr, nullptr, nullptr, &f);
 }
 
 int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* cond_nchw, int cond_channels,
@@ -1235,12 +1262,11 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
     // ... with the weights pre-split into bf16 planes (what a plan does, in its derived buffer): derived here, behind the split-K
     // slabs in `scratch` (sr3_conv_scratch_bytes accounts for them)
     c.igemm_split = 1; tile_cfg -= 17;
-    const size_t numel = (size_t)Cout * ksize * ksize * (c.C0 + c.C1);
     const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
-    const size_t wb = igemm_wsplit_floats(numel) * sizeof(float);
+    const size_t wb = igemm_wsplit_floats(Cout, ksize * ksize, c.C0 + c.C1) * sizeof(float);
     if (!scratch || scratch_bytes < slab + wb) { set_error("conv: scratch too small for the pre-split weights (%zu < %zu)", scratch_bytes, slab + wb); return SR3_E_NOMEM; }
     float* q = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab);
-    const int rc = igemm_split_weights(w, numel, q, static_cast<hipStream_t>(stream));
+    const int rc = igemm_split_weights(w, Cout, ksize * ksize, c.C0 + c.C1, q, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     c.w_split = q;
     scratch_bytes = slab;
@@ -1334,7 +1360,7 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
   if (tile_cfg >= 18 && tile_cfg <= 21) {      // + the pre-split weights behind the slabs
     c.igemm_split = 1; tile_cfg -= 17;
-    extra = igemm_wsplit_floats((size_t)Cout * ksize * ksize * Cin) * sizeof(float);
+    extra = igemm_wsplit_floats(Cout, ksize * ksize, Cin) * sizeof(float);
   }
   // the entry does not know the stride: take the larger of the stride-1 (halo kernel eligible) and the im2col sizing
   const size_t a = conv_splitk_bytes(c, tile_cfg, ksplit);

@@ -114,15 +114,14 @@ struct sr3_plan {
   int attn_split = 1;        // SelfAttention's two contractions on the 3 x bf16 split instantiation of k_attention_v2 (round 5)
   int gemm_tile = 0;         // A/B knob: force this im2col tile (1-4) on every conv of that kernel; 0 = conv_pick's choice
   int gemm_split = 1;        // the im2col kernel (1x1 and stride-2 convs) on its 3 x bf16 split instantiations (conv_igemm.hip)
-  int gemm_wpre = 0;         // 1: ... reading their weights pre-split (three bf16 planes in the derived buffer). Measured SLOWER in the
-                             // forward (1.59 vs 1.50 ms over the 33 launches, profiles/r05c_*: 1.5x the weight bytes, three loads per
-                             // quad) -- off by default, kept as tiles 18-21 at the ABI and as this A/B knob
+  int gemm_wpre = 1;         // 1: ... reading their weights pre-split AND in MFMA fragment order from the derived buffer, straight from global
+                             // memory (round 6: no LDS staging of the weights; tiles 18-21 at the ABI).  0: weights split while staged (14-17)
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;
   std::map<size_t, size_t> derived_of;     // weight arena offset -> float offset in the derived buffer
   // ... and, plan option gemm_split, the 1x1 / stride-2 weights of the im2col SPLIT tiles as three bf16 planes (conv_igemm.hip)
-  struct WSplit { size_t w, numel, off; };
+  struct WSplit { size_t w; int Cout, taps, Cin; size_t off; };
   std::vector<WSplit> wsplits;
   std::map<size_t, size_t> wsplit_of;      // weight arena offset -> float offset in the derived buffer
   size_t derived_floats = 0;
@@ -162,7 +161,7 @@ Regions infer_regions(const sr3_plan* P);
 int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
                 const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st, hipEvent_t* ev, hipEvent_t* mid,
-                const DropCfg* drop = nullptr);
+                const DropCfg* drop = nullptr, const StepFuse* fuse = nullptr);
 int build_train(sr3_plan* P, int B, int cond_channels);
 void layout_derived(sr3_plan* P);
 }  // namespace sr3

@@ -1,6 +1,8 @@
 // HBM-bound helpers of the SR3 / DDPM hot path (gfx950): GroupNorm statistics and folding,
 // the 6->C input conv (NCHW -> NHWC), the C->3 output Block (NHWC -> NCHW), the noise-level /
 // timestep embedding with every FiLM projection, and the fused reverse-step / q_sample updates.
+#include <string.h>
+
 #include "sr3_common.h"
 
 namespace sr3 {
@@ -409,11 +411,14 @@ int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, i
 // ---------------------------------------------------------------------------------------------
 constexpr int OT_H = 8, OT_W = 32, OT_CK = 16, OT_LD = 20;
 // COUT: output channels (1..4); FULL: C is a multiple of the 16-channel chunk (no per-quad bound checks)
-template <int COUT, bool FULL>
+// FUSE (sr3_reverse_step): the reverse-step update of the image this eps belongs to in the epilogue -- the element a thread produces IS the
+// element of eps the elementwise update (sr3 diffusion.py:141-149,162-174) needs, in the same NCHW position -- with k_p_sample_update's
+// separately rounded operations (bit-identical to the two-kernel form), and the loop counter's decrement by one thread
+template <int COUT, bool FULL, bool FUSE>
 __global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__ x, const float* __restrict__ ss,
                                                         int B, int H, int W, int C, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int Cout,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, const StepFuse f) {
   __shared__ f32x4 tile_v[(OT_H + 2) * (OT_W + 2) * OT_LD / 4];
   float* tile = reinterpret_cast<float*>(tile_v);
   const int tid = threadIdx.x;
@@ -466,22 +471,45 @@ __global__ __launch_bounds__(256) void k_conv_out_nchw(const float* __restrict__
     }
   }
   const int oh = h0 + ty, ow = w0 + tx;
+  int t = 0;
+  float ca = 0.f, cbb = 0.f, c1 = 0.f, c2 = 0.f, sg = 0.f;
+  if (FUSE) {
+    t = f.step_cur[0];
+    ca = f.tb.a[t]; cbb = f.tb.b[t]; c1 = f.tb.c1[t]; c2 = f.tb.c2[t]; sg = f.tb.sigma[t];
+    if (blockIdx.x == 0 && tid == 0) f.step_next[0] = t - 1;       // (nobody reads this slot before the next step's first kernel)
+  }
   if (oh < H && ow < W) {
 #pragma unroll
-    for (int co = 0; co < COUT; ++co)
-      out[(((size_t)b * Cout + co) * H + oh) * W + ow] = acc[co] + (bias ? bias[co] : 0.f);
+    for (int co = 0; co < COUT; ++co) {
+      const size_t idx = (((size_t)b * Cout + co) * H + oh) * W + ow;
+      const float e = acc[co] + (bias ? bias[co] : 0.f);
+      if (!FUSE || out) out[idx] = e;
+      if (FUSE) {
+        const float xv = f.x[idx], zv = f.z ? f.z[idx] : 0.f;
+        float x0 = sub_rn(mul_rn(ca, xv), mul_rn(cbb, e));
+        if (f.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float mean = add_rn(mul_rn(c1, x0), mul_rn(c2, xv));
+        f.x[idx] = add_rn(mean, mul_rn(zv, sg));
+      }
+    }
   }
 }
 
 int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, const float* w, const float* bias,
-                  int Cout, float* out_nchw, hipStream_t st) {
+                  int Cout, float* out_nchw, hipStream_t st, const StepFuse* fuse) {
   if (Cout > 4 || Cout < 1) { set_error("conv_out: Cout %d > 4 unsupported", Cout); return SR3_E_UNSUPPORTED; }
   if (C & 3) { set_error("conv_out: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
+  if (!fuse && !out_nchw) { set_error("conv_out: null output"); return SR3_E_BADARG; }
   const int tiles = ((W + OT_W - 1) / OT_W) * ((H + OT_H - 1) / OT_H) * B;
+  StepFuse f;
+  memset(&f, 0, sizeof(f));
+  if (fuse) f = *fuse;
+#define SR3_CO_LAUNCH3(N, FU, FS)                                                                                            \
+  hipLaunchKernelGGL((k_conv_out_nchw<N, FU, FS>), dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw, f);
 #define SR3_CO_LAUNCH(N)                                                                                                    \
   {                                                                                                                          \
-    if (C % OT_CK == 0) hipLaunchKernelGGL((k_conv_out_nchw<N, true>), dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw); \
-    else hipLaunchKernelGGL((k_conv_out_nchw<N, false>), dim3(tiles), dim3(256), 0, st, x, ss, B, H, W, C, w, bias, Cout, out_nchw);            \
+    if (C % OT_CK == 0) { if (fuse) { SR3_CO_LAUNCH3(N, true, true) } else { SR3_CO_LAUNCH3(N, true, false) } }             \
+    else { if (fuse) { SR3_CO_LAUNCH3(N, false, true) } else { SR3_CO_LAUNCH3(N, false, false) } }                          \
   }
   switch (Cout) {
     case 1: SR3_CO_LAUNCH(1) break;
@@ -490,6 +518,7 @@ int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, c
     default: SR3_CO_LAUNCH(4) break;
   }
 #undef SR3_CO_LAUNCH
+#undef SR3_CO_LAUNCH3
   SR3_LAUNCH_CHECK("k_conv_out_nchw");
   return SR3_OK;
 }
@@ -511,6 +540,7 @@ __global__ __launch_bounds__(256) void k_embed(const EmbedParams p) {
   } else {
     lv = p.step_dev ? (float)p.step_dev[0] : (float)p.tstep[b];
   }
+  if (p.step_out && b == 0 && tid == 0) p.step_out[0] = p.step_dev[0];      // (sr3_reverse_step: the slot the step's tail reads)
   for (int k = tid; k < half; k += 256) {
     const float arg = lv * p.freq[k];
     enc[k] = sinf(arg);

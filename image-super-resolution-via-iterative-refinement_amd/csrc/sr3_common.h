@@ -193,8 +193,8 @@ size_t conv_splitk_bytes(const ConvParams& p, int tile_cfg, int ksplit);
 void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit);
 int splitk_rows_per_block(const ConvParams& p, bool stats);
 // pre-split weights of the im2col SPLIT instantiations: floats of the derived block for `numel` weights, and the transform
-size_t igemm_wsplit_floats(size_t numel);
-int igemm_split_weights(const float* w, size_t numel, float* out, hipStream_t st);
+size_t igemm_wsplit_floats(int Cout, int taps, int Cin);
+int igemm_split_weights(const float* w, int Cout, int taps, int Cin, float* out, hipStream_t st);
 // profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the
 // split-K reduce kernel (then resets the pointer).  Thread-local.
 void conv_set_mid_event(hipEvent_t ev);
@@ -256,9 +256,21 @@ int halo_stats_slices(const HaloGeom& g);
 int conv_in_stat_slices(int Cin, int H, int W, int Cout);
 int conv_in_nchw(const float* a, int Ca, const float* b, int Cb, int B, int H, int W, const float* w,
                  const float* bias, int Cout, float* out, double* ostat, hipStream_t st);
-// final Block: silu(gn(x)) -> conv3x3 C->Cout(<=4), NHWC in, NCHW out
+// fused reverse-step update (NCHW, elementwise): coef = {a, b, c1, c2, sigma} tables of length T
+struct StepTables { const float* a; const float* b; const float* c1; const float* c2; const float* sigma; };
+// the tail of one reverse step folded into the output conv's epilogue (sr3_reverse_step): x <- p_sample update(x, eps, z, t) with
+// t = *step_cur, the same separately rounded operations as k_p_sample_update (bit-identical), and *step_next = t - 1 (one thread)
+struct StepFuse {
+  float* x;               // [B, Cout, H, W] in / out
+  const float* z;         // noise or null (= 0)
+  StepTables tb;
+  const int* step_cur;    // t of this step (written by the embedding kernel of the same forward)
+  int* step_next;         // t of the next step
+  int clip;
+};
+// final Block: silu(gn(x)) -> conv3x3 C->Cout(<=4), NHWC in, NCHW out (out_nchw may be null when `fuse` is given)
 int conv_out_nchw(const float* x, const float* ss, int B, int H, int W, int C, const float* w,
-                  const float* bias, int Cout, float* out_nchw, hipStream_t st);
+                  const float* bias, int Cout, float* out_nchw, hipStream_t st, const StepFuse* fuse = nullptr);
 // noise-level / timestep embedding + MLP + all FiLM projections
 struct EmbedParams {
   int variant;            // 0 sr3 (continuous level), 1 ddpm (integer t)
@@ -267,6 +279,7 @@ struct EmbedParams {
   const int64_t* tstep;   // [B] (ddpm) or null
   const float* level_table;  // sr3: level = level_table[step_dev[0] + 1] when step_dev != null
   const int* step_dev;    // device step counter (graph replay) or null
+  int* step_out;          // optional: block 0 copies *step_dev here (sr3_reverse_step: the slot the step's tail kernel reads)
   const float* freq;      // [inner/2] frequency table
   const float* w1; const float* b1;   // [4*inner][inner], [4*inner]
   const float* w2; const float* b2;   // [inner][4*inner], [inner]
@@ -279,8 +292,6 @@ int embed_forward(const EmbedParams& p, hipStream_t st);
 // single-head attention over NHWC qkv [B][N][3C] -> out [B][N][C]
 // split != 0: the staging-free kernel's 3 x bf16 split instantiation where the shape takes that kernel (fp32 MFMA otherwise)
 int attention_forward(const float* qkv, int B, int N, int C, float* out, hipStream_t st, int split = 0);
-// fused reverse-step update (NCHW, elementwise): coef = {a, b, c1, c2, sigma} tables of length T
-struct StepTables { const float* a; const float* b; const float* c1; const float* c2; const float* sigma; };
 int p_sample_update(float* x, const float* eps, const float* z, StepTables tb, const int* step_dev,
                     const int64_t* t_per_sample, int step_host, int B, int per_image, hipStream_t st, bool clip = true);
 int step_decrement(int* step_dev, hipStream_t st);

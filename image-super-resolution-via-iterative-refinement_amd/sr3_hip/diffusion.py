@@ -179,17 +179,20 @@ class EngineDiffusion(nn.Module):
             st = dict(img=torch.empty(shape, device=dev), z=torch.empty(shape, device=dev),
                       eps=torch.empty(shape, device=dev),
                       cond=None if cond_shape is None else torch.empty(cond_shape, device=dev),
-                      step=torch.zeros(1, dtype=torch.int32, device=dev), graph=None, ws=E.Workspace())
+                      step=torch.zeros(2, dtype=torch.int32, device=dev), graph=None, ws=E.Workspace())      # [scratch, t]
             self._loop_cache = {key: st}       # keep one shape alive at a time
         return st
 
     def _one_step(self, st, draw_noise=True):
+        """One iteration of the loop: z ~ N(0, 1) (torch's graph-safe Philox), then sr3_reverse_step -- UNet forward with the p_sample
+        update and the counter decrement inside the output conv's kernel (round 6; before: three calls, two more graph nodes).
+        st['eps'] keeps the step's eps for the parity checks that read it."""
         if draw_noise:
             st['z'].normal_()
-        self.denoise_fn(st['img'], None, cond=st['cond'], level_table=self._level_table, step_dev=st['step'],
-                        out=st['eps'], ws=st['ws'])
-        self._step_update(st['img'], st['eps'], st['z'], step_dev=st['step'])
-        L.check(L.load().sr3_step_decrement(L.ptr(st['step']), self._stream(st['img'].device)))
+        tables = (self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                  self.posterior_mean_coef2, self._sigma)
+        self.denoise_fn.reverse_step(st['img'], st['z'], tables, st['step'], cond=st['cond'], level_table=self._level_table,
+                                     clip_denoised=True, eps_out=st['eps'], ws=st['ws'])
 
     def _capture(self, st):
         dev = st['img'].device
@@ -236,7 +239,7 @@ class EngineDiffusion(nn.Module):
             st['img'].copy_(torch.randn(shape, device=dev))
         if cond is not None:
             st['cond'].copy_(cond)
-        st['step'].fill_(T - 1)
+        st['step'].fill_(T - 1)                # (slot 1 = t of the next step; slot 0 is the step's scratch copy)
         n_snap = sum(1 for i in range(T) if i % inter == 0)
         B = shape[0]
         ret = torch.empty((B * (n_snap + 1),) + shape[1:], device=dev)

@@ -144,6 +144,30 @@ class Workspace(object):
         return self.buf[off:off + need], need
 
 
+def reverse_step(plan, arena, freq, ws, x, z, tables, step2, cond=None, level_table=None, clip_denoised=True, eps_out=None):
+    """One whole reverse step in place on `x` (sr3_reverse_step): eps = UNet(cat([cond, x], 1), level(t)); x <- p_sample update;
+    t <- t - 1, with t = step2[1] (int32 tensor of two).  `tables` = (a, b, c1, c2, sigma) schedule tables on the device."""
+    if not x.is_cuda or not x.is_contiguous() or x.dtype != torch.float32:
+        raise L.Sr3Error('reverse_step needs a contiguous fp32 GPU tensor (got %s, %s); there is no CPU fallback' % (x.device, x.dtype))
+    B = x.shape[0]
+    cc = 0
+    if cond is not None:
+        cond = cond.contiguous()
+        cc = cond.shape[1]
+    if x.shape[1] + cc != plan.in_channel or x.shape[1] != plan.out_channel or x.shape[2] != plan.image_size or x.shape[3] != plan.image_size:
+        raise L.Sr3Error('input shape %s (+%d cond channels) does not match the plan (in_channel %d, out_channel %d, size %d)'
+                         % (tuple(x.shape), cc, plan.in_channel, plan.out_channel, plan.image_size))
+    if step2.dtype != torch.int32 or step2.numel() != 2 or step2.device != x.device:
+        raise L.Sr3Error('step2 must be two int32 on the device of x')
+    wsbuf, need = ws.get(plan, B, x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    a, b, c1, c2, sg = tables
+    L.check(plan.lib.sr3_reverse_step(plan.handle, L.ptr(x), L.ptr(cond), cc, L.ptr(freq), L.ptr(level_table), L.ptr(step2),
+                                      L.ptr(arena), L.ptr(wsbuf), need, L.ptr(z), L.ptr(a), L.ptr(b), L.ptr(c1), L.ptr(c2), L.ptr(sg),
+                                      1 if clip_denoised else 0, L.ptr(eps_out), B, C.c_void_p(stream)))
+    return x
+
+
 def unet_forward(plan, arena, freq, ws, x, cond=None, noise_level=None, timestep=None, level_table=None,
                  step_dev=None, out=None):
     """eps = UNet(cat([cond, x], 1), level)   (all tensors on the GPU, fp32, NCHW contiguous)."""

@@ -75,6 +75,7 @@ SIGNATURES = {
     'sr3_p_sample_step': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     'sr3_p_sample_step_ex': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'sr3_step_decrement': (_I, [_P, _P]),
+    'sr3_reverse_step': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P]),
     'sr3_q_sample': (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     'sr3_train_workspace_bytes': (_Z, [_P, _I, _I]),
     'sr3_train_step': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, C.c_float, C.c_float, C.c_uint,

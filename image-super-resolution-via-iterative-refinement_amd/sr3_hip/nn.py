@@ -187,6 +187,13 @@ class EngineUNet(nn.Module):
         return E.unet_forward(self.plan, self.arena.data, self.freq, self._ws if ws is None else ws, x, cond=cond,
                               level_table=level_table, step_dev=step_dev, out=out, **kw)
 
+    def reverse_step(self, x, z, tables, step2, *, cond=None, level_table=None, clip_denoised=True, eps_out=None, ws=None):
+        """One whole iteration of the reverse loop in place on `x` (engine.reverse_step): what `GaussianDiffusion.p_sample_loop`
+        captures into its hipGraph."""
+        self.ensure_derived()
+        return E.reverse_step(self.plan, self.arena.data, self.freq, self._ws if ws is None else ws, x, z, tables, step2,
+                              cond=cond, level_table=level_table, clip_denoised=clip_denoised, eps_out=eps_out)
+
     # ---- training step (forward + backward inside the engine) ------------------------------------
     def train_step(self, hr, cond, z, ca, cb, level, tstep, grad_scale, drop_seed=None):
         """One fused forward + backward: returns the sum-reduced loss (0-dim tensor, summed over all data-parallel

@@ -201,6 +201,23 @@ int sr3_p_sample_step_ex(float* x_nchw, const float* eps_nchw, const float* z_nc
 /* *step_dev -= 1 on the stream (loop counter of p_sample_loop, diffusion.py:193, for graph replay) */
 int sr3_step_decrement(int* step_dev, void* stream);
 
+/* One WHOLE iteration of the reference's reverse loop (model/sr3_modules/diffusion.py:190-196 `for i in reversed(range(T)): img = p_sample(img, i, ...)`
+ * with p_sample = :169-174, p_mean_variance :151-167; model/ddpm_modules/diffusion.py:200-215) as one capturable call:
+ *   eps = UNet(cat(cond, x), level(t))  ;  x <- p_sample update of (x, eps, z, t)  ;  t <- t - 1
+ * = sr3_unet_forward + sr3_p_sample_step_ex + sr3_step_decrement, with the last two inside the output convolution's kernel (the thread
+ * that produces an element of eps updates the same element of x; separately rounded operations, bit-identical to the three-call form):
+ * two kernel nodes fewer per replayed step.
+ *   x_nchw      : [B, C, S, S] the image, in / out
+ *   step2_dev   : TWO ints.  step2_dev[1] = t of this step on entry (the caller sets it to T - 1 before the first step) and t - 1 on
+ *                 completion; step2_dev[0] is scratch (the step's first kernel copies t there for its last one).  t must stay >= 0.
+ *   level_table : SR3: level = level_table[t + 1] (sqrt_alphas_cumprod_prev); DDPM: ignored (the timestep is t)
+ *   z_nchw      : the step's noise or NULL (= 0); tab_*: the schedule tables of sr3_p_sample_step (sigma[0] = 0 replaces `t > 0`)
+ *   eps_out_nchw: NULL, or where to also store eps (parity checks) */
+int sr3_reverse_step(sr3_plan* plan, float* x_nchw, const float* cond_nchw, int cond_channels, const float* freq,
+                     const float* level_table, int* step2_dev, const float* params, void* workspace, size_t workspace_bytes,
+                     const float* z_nchw, const float* tab_a, const float* tab_b, const float* tab_c1, const float* tab_c2,
+                     const float* tab_sigma, int clip_denoised, float* eps_out_nchw, int batch, void* stream);
+
 /* q_sample (model/sr3_modules/diffusion.py:212-219; model/ddpm_modules/diffusion.py:259-267):
  * out = ca[b] * x0 + cb[b] * z */
 int sr3_q_sample(const float* x0, const float* z, const float* ca, const float* cb, int batch,

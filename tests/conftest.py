@@ -13,6 +13,17 @@ for p in (ROOT, PKG):
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'experiments: needs a library built with -DSR3_EXPERIMENTS (skipped otherwise)')
+    config.addinivalue_line('markers', 'slow: full-length variants of tests that also run shortened by default; selected only when the '
+                                       '-m expression names `slow` (e.g. -m "gpu and slow") or SR3_SLOW=1')
+
+
+def pytest_collection_modifyitems(config, items):
+    if 'slow' in (config.getoption('-m') or '') or os.environ.get('SR3_SLOW') == '1':
+        return
+    skip = pytest.mark.skip(reason='slow: full-length variant (run with -m "gpu and slow"); its shortened form runs by default')
+    for it in items:
+        if it.get_closest_marker('slow') is not None:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope='session')

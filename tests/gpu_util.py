@@ -61,6 +61,31 @@ def conv_call(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, re
     return nchw(out).cpu(), (None if stats is None else stats.cpu().sum(1))
 
 
+def wino_expected_refusal(B, Cin, H, W, ups, tile, ksplit, k=3, stride=1):
+    """Which error message the Winograd kernels (tile 11 / 12: conv3x3_wino.hip, 13: conv3x3_wino2.hip) MUST raise for this problem,
+    or None when they must run -- the geometric rules of wino_geometry / conv3x3_wino_forward restated, so that a test can assert
+    the refusal instead of skipping on whatever message came back (a production tile that raises unexpectedly then FAILS)."""
+    Ho, Wo = H << ups, W << ups
+    if k != 3 or stride != 1:
+        return 'does not fit'
+    nb4 = tile != 13 and Ho == 8 and Wo == 8 and ups == 0 and B % 4 == 0 and Cin > 16
+    if tile == 13:
+        if Wo < 16 or Wo % 16 or Ho % 8:
+            return 'does not fit'
+    elif not nb4 and (Wo < 16 or Wo % 16 or Ho % 16):
+        return 'does not fit'
+    if ksplit == 0:
+        return None
+    chunks = -(-Cin // 16)
+    if nb4 and ksplit < 2:
+        return 'split-K only'
+    if -(-chunks // ksplit) > (16 if nb4 else 64):
+        return 'per K split'
+    if ksplit > 1 and (ksplit - 1) * -(-chunks // ksplit) >= chunks:
+        return 'empty split'
+    return None
+
+
 def conv_ref(src0, src1, w, bias=None, ss=None, act=0, film=None, res0=None, res1=None, ups=0, stride=1):
     """float64 reference of the same fused op."""
     x = src0 if src1 is None else torch.cat([src0, src1], 1)

@@ -82,7 +82,7 @@ def test_unet_forward_exact_fp32_option(name):
     d = G.dev()
     x, t = torch.from_numpy(g['unet/x']).to(d), torch.from_numpy(g['unet/time']).to(d)
     assert un.plan.options.get('wino_split', 1) == 1 and un.plan.options.get('gemm_split', 1) == 1
-    split_tiles = (12, 14, 15, 16, 17, 18, 19, 20, 21)
+    split_tiles = (12, 13, 14, 15, 16, 17, 18, 19, 20, 21)
     has_split = any(o['tile_cfg'] in split_tiles for o in un.plan.op_list(x.shape[0]))
     assert has_split, 'the default plan of %s has no conv on a split instantiation' % name
     e0 = un(x, t).clone()
@@ -158,6 +158,45 @@ def test_p_sample_without_clipping(name):
         G.assert_close(r.cpu(), torch.from_numpy(n['%s/step/%d' % (name, t)]), tol=2e-5 * scale, what='%s step %d' % (name, t))
         clipped = m.netG.p_mean_variance(x=x, t=tt, clip_denoised=True, **kw)[0]
         assert (clipped.cpu() - torch.from_numpy(n['%s/mean/%d' % (name, t)])).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize('clip', [True, False])
+@pytest.mark.parametrize('name', NAMES)
+def test_reverse_step_one_call_equals_three(name, clip):
+    """sr3_reverse_step (the whole loop iteration as one capturable call: the p_sample update and the counter decrement inside the
+    output conv's kernel) against sr3_unet_forward + sr3_p_sample_step_ex + sr3_step_decrement on the same inputs: eps and the new
+    image BIT-equal, the counter decremented; and against the reference's own step outputs where the golden file holds them."""
+    m, g, sd = build(name)
+    d = G.dev()
+    netG = m.netG
+    un = netG.denoise_fn
+    cond = torch.from_numpy(g['loop/sr']).to(d) if CONDITIONAL[name] else None
+    zs = torch.from_numpy(g['loop/zs']).to(d)
+    xs = torch.from_numpy(g['step/x']).to(d)
+    T = int(g['meta/T'])
+    tables = (netG.sqrt_recip_alphas_cumprod, netG.sqrt_recipm1_alphas_cumprod, netG.posterior_mean_coef1,
+              netG.posterior_mean_coef2, netG._sigma)
+    for t in sorted({T - 1, T // 2, 1, 0}):
+        # three calls
+        step1 = torch.full((1,), t, dtype=torch.int32, device=d)
+        eps3 = un(xs, None, cond=cond, level_table=netG._level_table, step_dev=step1)
+        x3 = xs.clone()
+        netG._step_update(x3, eps3, zs[t], step_dev=step1, clip_denoised=clip)
+        # one call
+        step2 = torch.tensor([-77, t], dtype=torch.int32, device=d)
+        x1 = xs.clone()
+        eps1 = torch.empty_like(eps3)
+        un.reverse_step(x1, zs[t], tables, step2, cond=cond, level_table=netG._level_table, clip_denoised=clip, eps_out=eps1)
+        assert torch.equal(eps1, eps3), 'eps differs at t = %d' % t
+        assert torch.equal(x1, x3), 'image differs at t = %d' % t
+        assert step2.tolist() == [t, t - 1]
+        if clip and ('step/%d' % t) in g:
+            G.assert_close(x1.cpu(), torch.from_numpy(g['step/%d' % t]), what='%s reverse step %d' % (name, t))
+        # eps_out is optional
+        x0 = xs.clone()
+        step2 = torch.tensor([0, t], dtype=torch.int32, device=d)
+        un.reverse_step(x0, zs[t], tables, step2, cond=cond, level_table=netG._level_table, clip_denoised=clip)
+        assert torch.equal(x0, x3)
 
 
 @pytest.mark.parametrize('name', NAMES)
@@ -261,7 +300,7 @@ def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
     t = torch.from_numpy(g['unet/time']).to(d)
     ref = torch.from_numpy(g['unet/eps'])
     G.assert_close(un(x, t).cpu(), ref, what='before')
-    assert any(o['tile_cfg'] in (11, 12) for o in un.plan.op_list(x.shape[0])), 'the plan has no Winograd op: nothing derived to test'
+    assert any(o['tile_cfg'] in (11, 12, 13) for o in un.plan.op_list(x.shape[0])), 'the plan has no Winograd op: nothing derived to test'
     # (1) raw C-ABI call after an invalidation: loud failure; after prepare: fine again
     lib = un.plan.lib
     L.check(lib.sr3_plan_invalidate_derived(un.plan.handle))
@@ -280,7 +319,7 @@ def test_stale_derived_filters_fail_loudly_and_option_toggle_rebuilds():
     G.assert_close(un(x, t).cpu(), ref, what='after weights_changed')
     # (2) option toggle after a forward
     un.plan.set_option('winograd', 0)
-    assert not any(o['tile_cfg'] in (11, 12) for o in un.plan.op_list(x.shape[0]))
+    assert not any(o['tile_cfg'] in (11, 12, 13) for o in un.plan.op_list(x.shape[0]))
     G.assert_close(un(x, t).cpu(), ref, what='winograd off')
     un.plan.set_option('winograd', 1)
     G.assert_close(un(x, t).cpu(), ref, what='winograd on again')
