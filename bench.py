@@ -43,9 +43,9 @@ PKG = os.path.join(ROOT, 'image-super-resolution-via-iterative-refinement_amd')
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (~2.5 PF)
-PROFILE_ROUND = 'r05'
-# sr3_unet_forward_profile op kinds (plan.hip): Winograd fp32 one-image / four-image tile, SPLIT one-image / four-image tile,
-# four-wave SPLIT kernel; im2col SPLIT tiles 14-17
+PROFILE_ROUND = 'r06'
+# sr3_unet_forward_profile op kinds (plan.hip): Winograd fp32 one-image / four-image tile, SPLIT one-image / four-image tile (8-wave
+# kernel), 575 = the two-workgroups-per-CU SPLIT kernel of conv3x3_wino2.hip; im2col SPLIT tiles 14-17
 WINO_KINDS = (455, 465, 555, 565, 575)
 WINO_SPLIT_KINDS = (555, 565, 575)
 IGEMM_SPLIT_KINDS = (651, 652, 653, 654)              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
@@ -344,7 +344,7 @@ def roofline_from_profile(netG, x, cond, reps=3):
              355: 'k_conv3x3_halo<4,2,false,false,1,2>', 357: 'k_conv3x3_halo<4,2,true,false,1,2>',
              455: 'k_conv3x3_wino<0,false,false,false>', 465: 'k_conv3x3_wino<0,false,true,false>',
              555: 'k_conv3x3_wino<0,false,false,true>', 565: 'k_conv3x3_wino<0,false,true,true>',
-             575: 'k_conv3x3_wino4<0,false>'}
+             575: 'k_conv3x3_wino2<0>'}
     total_ms = sum(a[0] for a in agg.values()) / reps
     dom = max((k for k in names if k in agg), key=lambda k: agg[k][0])     # largest share of the forward
     t_ms, flops, launches = agg[dom]
@@ -515,7 +515,8 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
         dt = float(tt.item())
     ms = dt / steps * 1e3
     fl = 3.0 * m.netG.denoise_fn.plan.forward_flops(batch)
-    return {'metric': '%s training images/sec (p_losses + backward + Adam)' % c['title'], 'value': world * batch / (ms * 1e-3),
+    return {'roofline': train_roofline(cfg_name, ms),
+            'metric': '%s training images/sec (p_losses + backward + Adam)' % c['title'], 'value': world * batch / (ms * 1e-3),
             'unit': 'images/s', 'steps_per_s': 1e3 / ms, 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
             'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': c['unet']['dropout'],
             'optimizer': 'Adam lr %g' % c['lr'],
@@ -527,6 +528,46 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix'],
             **({'stub': True, 'gradient_buckets_walked': m.buckets_walked,
                 'gradient_buckets_per_step': len(m.red.buckets) if m.red else 0} if STUB else {})}
+
+
+def train_roofline(cfg_name, ms_live):
+    """`roofline` of the training leg: the training step has no per-launch event table (one engine call), so the dominant kernel, its
+    share of the step and its matrix-pipe utilisation come from the committed rocprofv3 passes of the SAME step on the round's final
+    tree (profiles/<round>_train_kernel_stats.csv = --kernel-trace --stats of tools/gpu_probe.py --train 64; <round>_train_sq_counters.json
+    = its own --pmc SQ pass): frac = SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles) = executed MFMA rate / the pipe's roof."""
+    if cfg_name != 'sr3_16_128':
+        return None
+    import csv
+    try:
+        rows = list(csv.DictReader(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_train_kernel_stats.csv'))))
+        rows = [r for r in rows if 'sr3::' in r['Name']]
+        tot = sum(float(r['TotalDurationNs']) for r in rows)
+        steps = None
+        by = sorted(rows, key=lambda r: -float(r['TotalDurationNs']))
+        with open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_train_sq_counters.json')) as f:
+            sq = json.load(f)
+
+        def key(name):
+            import re
+            return re.sub(r'\(.*$', '', name).replace('void ', '').strip()
+        top = []
+        for r in by[:6]:
+            c = sq.get(key(r['Name']), {})
+            top.append({'kernel': key(r['Name']), 'share_of_step_kernel_time': float(r['TotalDurationNs']) / tot,
+                        'avg_launch_us': float(r['AverageNs']) / 1e3, 'calls_in_profile': int(r['Calls']),
+                        'mfma_busy': c.get('mfma_busy'), 'wait_any': c.get('wait_any'), 'wait_inst': c.get('wait_inst')})
+        d = top[0]
+        split = ('wgrad_split' in d['kernel']) or ('wino' in d['kernel']) or ('igemm' in d['kernel'])
+        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        return {'bound': 'mfma', 'kernel': d['kernel'], 'frac': d['mfma_busy'], 'peak': peak, 'unit': 'TFLOP/s',
+                'achieved': (d['mfma_busy'] * peak if d['mfma_busy'] is not None else None),
+                'share_of_step_kernel_time': d['share_of_step_kernel_time'], 'avg_launch_us': d['avg_launch_us'],
+                'top_kernels': top, 'ms_per_step_live': ms_live,
+                'source': 'profiles/%s_train_kernel_stats.csv + %s_train_sq_counters.json (rocprofv3 passes of the same step on the '
+                          "round's final tree); achieved = SQ_VALU_MFMA_BUSY_CYCLES fraction x the pipe's dense peak for the kernel's MFMA "
+                          'type (bf16 for the 3 x bf16 split kernels: six products per fp32 multiply-add)' % (PROFILE_ROUND, PROFILE_ROUND)}
+    except (OSError, KeyError, ValueError, IndexError) as e:
+        return {'error': 'no committed training counters for %s: %s' % (PROFILE_ROUND, e)}
 
 
 def headline_dtype(plan, batch):

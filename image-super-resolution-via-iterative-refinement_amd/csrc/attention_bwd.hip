@@ -3,8 +3,11 @@
 //   S = Q K^T / sqrt(C), P = softmax(S), O = P V
 //   dV = P^T dO ; dP = dO V^T ; dS = P o (dP - rowsum(dP o P)) ; dQ = dS K / sqrt(C) ; dK = dS^T Q / sqrt(C)
 // One workgroup owns 32 query rows of one image: it recomputes the score strip P[32][N] (as the
-// forward does), builds the strip of dS / sqrt(C) next to it in LDS, writes its rows of dQ, and adds
-// its contribution to dK and dV (all keys) with fp32 atomics -- dqkv must be zero on entry.
+// forward does), builds the strip of dS / sqrt(C) next to it in LDS, writes its rows of dQ, and hands
+// its contribution to dK and dV (all keys) to a slab of its own -- slab[query block][B][N][2C], plain stores, every
+// element written exactly once -- which k_attn_dkv_reduce sums in query-block order: no atomics, no memset, bitwise
+// reproducible (round 6; the training plan always provides the slabs).  Without slabs (the per-op ABI entry called
+// with no scratch) the contributions are added with fp32 atomics as before -- dqkv is zeroed first.
 // Layouts as in attention.hip: qkv / dqkv [B][N][3C] (q|k|v), dout [B][N][C].  fp32 MFMA throughout.
 //
 // BLOCKED = true (N too large for two full-width strips in 160 KB of LDS, e.g. the N = 1024 mid block of
@@ -12,6 +15,8 @@
 // by block for the row maxima / exp-sums (online softmax), rowsum(dP o P) is taken as rowsum(dO o O) from
 // the saved forward output, and the main pass handles each key block independently: its rows of dQ are
 // accumulated in place across blocks (this workgroup owns them), dK / dV go out with atomics as before.
+#include <algorithm>
+
 #include "sr3_common.h"
 #include "train.h"
 
@@ -25,7 +30,7 @@ constexpr int AB_V_STAGE = 32 * AB_LDV;
 template <int NSTAGE, bool BLOCKED>
 __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                         const float* __restrict__ o_fwd, int N, int C, int KB,
-                                                        float* __restrict__ dqkv) {
+                                                        float* __restrict__ dqkv, float* __restrict__ slab) {
   extern __shared__ f32x4 smem_v[];
   float* smem = reinterpret_cast<float*>(smem_v);
   const int LDS_S = (BLOCKED ? KB : ((N + 31) & ~31)) + 4;
@@ -308,8 +313,14 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
               for (int r = 0; r < 16; ++r) {
                 const int key = kb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (key < NK) {
-                  atomicAdd(&dqb[(size_t)(kbase + key) * rs3 + C + c], ak[r]);
-                  atomicAdd(&dqb[(size_t)(kbase + key) * rs3 + 2 * C + c], av[r]);
+                  if (slab) {
+                    float* sl = slab + (((size_t)blockIdx.x * gridDim.y + b) * N + (kbase + key)) * (2 * C);
+                    sl[c] = ak[r];
+                    sl[C + c] = av[r];
+                  } else {
+                    atomicAdd(&dqb[(size_t)(kbase + key) * rs3 + C + c], ak[r]);
+                    atomicAdd(&dqb[(size_t)(kbase + key) * rs3 + 2 * C + c], av[r]);
+                  }
                 }
               }
             }
@@ -320,7 +331,23 @@ __global__ __launch_bounds__(256) void k_attention_bwd(const float* __restrict__
   }
 }
 
-int attention_backward(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv, hipStream_t st) {
+// dK / dV = the query blocks' slabs summed in block order (fixed order: bitwise reproducible); one thread per (b, key, channel quad of 2C)
+__global__ __launch_bounds__(256) void k_attn_dkv_reduce(const float* __restrict__ slab, int nqb, int B, int N, int C, float* __restrict__ dqkv) {
+  const size_t quads = (size_t)B * N * (2 * C / 4);
+  const size_t per = (size_t)B * N * 2 * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / (2 * C / 4);
+    const int c = (int)(i - row * (2 * C / 4)) * 4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(slab + i * 4);
+    for (int q = 1; q < nqb; ++q) a += *reinterpret_cast<const f32x4*>(slab + (size_t)q * per + i * 4);
+    *reinterpret_cast<f32x4*>(dqkv + row * (3 * C) + C + c) = a;
+  }
+}
+
+size_t attention_backward_scratch_bytes(int B, int N, int C) { return (size_t)((N + 31) / 32) * B * N * 2 * C * sizeof(float); }
+
+int attention_backward(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv, hipStream_t st,
+                       float* scratch, size_t scratch_bytes) {
   if (C & 3) { set_error("attention_bwd: C %% 4 != 0"); return SR3_E_UNSUPPORTED; }
   if ((double)B * N * 3.0 * C >= 2147483647.0) { set_error("attention_bwd: qkv exceeds 2^31 elements"); return SR3_E_UNSUPPORTED; }
   const size_t lds_max = 160 * 1024;
@@ -339,14 +366,22 @@ int attention_backward(const float* qkv, const float* dout, const float* out_fwd
     while (bytes(KB + 128, stage2) <= lds_max) KB += 128;
     smem = bytes(KB, stage2);
   }
-  SR3_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * N * 3 * C * sizeof(float), st));
+  const bool slabs = scratch != nullptr && scratch_bytes >= attention_backward_scratch_bytes(B, N, C);
+  if (scratch && !slabs) { set_error("attention_bwd: scratch too small for the dK / dV slabs (%zu < %zu)", scratch_bytes, attention_backward_scratch_bytes(B, N, C)); return SR3_E_NOMEM; }
+  if (!slabs) SR3_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * N * 3 * C * sizeof(float), st));        // (atomics path only)
   static std::atomic<uint64_t> attr_done[3];
   const int which = KB ? 2 : nstage - 1;
   auto kern = KB ? k_attention_bwd<2, true> : (nstage == 2 ? k_attention_bwd<2, false> : k_attention_bwd<1, false>);
   // the attribute is an upper bound: allow the whole LDS once per (instantiation, device)
   if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), (int)lds_max, attr_done[which])) return rc;
-  hipLaunchKernelGGL(kern, dim3((N + 31) / 32, B), dim3(256), smem, st, qkv, dout, out_fwd, N, C, KB, dqkv);
+  hipLaunchKernelGGL(kern, dim3((N + 31) / 32, B), dim3(256), smem, st, qkv, dout, out_fwd, N, C, KB, dqkv, slabs ? scratch : nullptr);
   SR3_LAUNCH_CHECK("k_attention_bwd");
+  if (slabs) {
+    const size_t quads = (size_t)B * N * (2 * C / 4);
+    int blocks = (int)std::min<size_t>((quads + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_attn_dkv_reduce, dim3(blocks), dim3(256), 0, st, scratch, (N + 31) / 32, B, N, C, dqkv);
+    SR3_LAUNCH_CHECK("k_attn_dkv_reduce");
+  }
   return SR3_OK;
 }
 
@@ -355,5 +390,11 @@ int attention_backward(const float* qkv, const float* dout, const float* out_fwd
 extern "C" int sr3_attention_bwd_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
                                      void* stream) {
   if (!qkv || !dout || !dqkv) { sr3::set_error("null argument"); return SR3_E_BADARG; }
-  return sr3::attention_backward(qkv, dout, out_fwd, B, N, C, dqkv, static_cast<hipStream_t>(stream));
+  return sr3::attention_backward(qkv, dout, out_fwd, B, N, C, dqkv, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+extern "C" size_t sr3_attention_bwd_scratch_bytes(int B, int N, int C) { return sr3::attention_backward_scratch_bytes(B, N, C); }
+extern "C" int sr3_attention_bwd_ex_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
+                                        void* scratch, size_t scratch_bytes, void* stream) {
+  if (!qkv || !dout || !dqkv || !scratch) { sr3::set_error("null argument"); return SR3_E_BADARG; }
+  return sr3::attention_backward(qkv, dout, out_fwd, B, N, C, dqkv, static_cast<hipStream_t>(stream), static_cast<float*>(scratch), scratch_bytes);
 }

@@ -871,6 +871,11 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
       max_bscratch = std::max(max_bscratch, conv_splitk_bytes(g, 0, 0));
     }
   }
+  for (const Rec& r : P->recs)                // ... and the dK / dV slabs of the attention backward (attention_bwd.hip)
+    if (r.kind == R_ATTN) {
+      const Tensor& o = P->ttens[r.o];
+      max_bscratch = std::max(max_bscratch, attention_backward_scratch_bytes(B, o.H * o.W, o.C));
+    }
   if (max_bscratch > P->t_scratch_bytes) {    // the forward's split-K region doubles as the backward's
     off -= al(P->t_scratch_bytes);
     P->t_scratch_bytes = max_bscratch;

@@ -114,8 +114,11 @@ struct sr3_plan {
   int attn_split = 1;        // SelfAttention's two contractions on the 3 x bf16 split instantiation of k_attention_v2 (round 5)
   int gemm_tile = 0;         // A/B knob: force this im2col tile (1-4) on every conv of that kernel; 0 = conv_pick's choice
   int gemm_split = 1;        // the im2col kernel (1x1 and stride-2 convs) on its 3 x bf16 split instantiations (conv_igemm.hip)
-  int gemm_wpre = 1;         // 1: ... reading their weights pre-split AND in MFMA fragment order from the derived buffer, straight from global
-                             // memory (round 6: no LDS staging of the weights; tiles 18-21 at the ABI).  0: weights split while staged (14-17)
+  int gemm_wpre = 0;         // 1: ... reading their weights pre-split AND in MFMA fragment order from the derived buffer, straight from global
+                             // memory (round 6's form: no LDS staging of the weights; tiles 18-21 at the ABI).  Measured SLOWER in the forward
+                             // again (1.50-1.52 vs 1.44-1.46 ms over the 33 launches, profiles/r06_gemm_wpre_fragment_major.txt: every wave
+                             // fetches its own fragments, 3x the weight traffic of one staged copy per workgroup, and the A staging that
+                             // bounds these launches is unchanged) -- off by default, an A/B knob.  0: weights split while staged (14-17)
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;

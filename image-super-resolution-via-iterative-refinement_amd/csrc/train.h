@@ -40,7 +40,10 @@ int conv_wgrad(const WgradParams& p, hipStream_t st);
 
 // Attention backward (attention_bwd.hip): qkv [B][N][3C], dout [B][N][C] -> dqkv [B][N][3C] (overwritten)
 // out_fwd (the forward attention output [B][N][C]) is only read by the key-blocked path (N too large for LDS strips)
-int attention_backward(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv, hipStream_t st);
+// scratch (attention_backward_scratch_bytes): dK / dV slabs per query block, summed in order -- no atomics, no memset; null: fp32 atomics
+size_t attention_backward_scratch_bytes(int B, int N, int C);
+int attention_backward(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv, hipStream_t st,
+                       float* scratch = nullptr, size_t scratch_bytes = 0);
 
 // Embedding / FiLM backward (small): see train_small.hip
 struct EmbedBwdParams {

@@ -142,7 +142,9 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       SR3_HIP(hipMemcpyAsync(grads + r.w, dwtmp, (size_t)P->out_ch * 9 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else if (r.kind == R_ATTN) {
       const Tensor& o = P->ttens[r.o];
-      rc = attention_backward(X.act(r.qkv), X.grad(r.o), X.act(r.o), B, o.H * o.W, o.C, X.grad(r.qkv), st);
+      // dK / dV through per-query-block slabs in the backward's scratch region, summed in block order: no atomics (round 6)
+      rc = attention_backward(X.act(r.qkv), X.grad(r.o), X.act(r.o), B, o.H * o.W, o.C, X.grad(r.qkv), st,
+                              X.at<float>(P->t_scratch_off), P->t_scratch_bytes);
       if (rc) return rc;
     } else if (r.kind == R_CONV_IN) {
       const Tensor& o = P->ttens[r.out];

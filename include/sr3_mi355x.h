@@ -320,6 +320,12 @@ int sr3_attention_ex_f32(const float* qkv, int B, int N, int C, float* out, int 
  * (the forward output) may be NULL when N <= ~480 -- larger N use a key-blocked pass that reads it */
 int sr3_attention_bwd_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
                           void* stream);
+/* ... bitwise reproducible: every 32-query block hands its dK / dV contribution to a slab of its own in `scratch`
+ * (sr3_attention_bwd_scratch_bytes(B, N, C) = ceil(N / 32) * B * N * 2C floats) and a second kernel sums the slabs in block
+ * order -- no atomics, no memset (sr3_attention_bwd_f32 adds with fp32 atomics).  What sr3_train_step runs. */
+size_t sr3_attention_bwd_scratch_bytes(int B, int N, int C);
+int sr3_attention_bwd_ex_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
+                             void* scratch, size_t scratch_bytes, void* stream);
 /* noise-level / timestep embedding + MLP + all FiLM rows (unet.py:18-50,179-184): see sr3_common.h */
 int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep,
                        const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,

@@ -175,25 +175,26 @@ def test_plan_launch_list_no_gpu():
         assert not o['fused_res_conv_cin']
         if o['tile_cfg'] in (11, 12) and o['h_out'] == 8:       # the four-image tile has no direct epilogue: always split-K, at most
             assert o['ksplit'] >= 2 and -(-o['cin'] // 16) <= 16 * o['ksplit'], o      # 16 chunks (256 channels) per split
-    # the im2col SPLIT tiles read their weights pre-split and in MFMA fragment order from the derived buffer by default (plan option
-    # gemm_wpre = 1, round 6: tiles 18-21, no LDS staging of the weights): three bf16 planes = 6 bytes per weight of the res_convs,
-    # attention projections and Downsample convs with Cout > 64; gemm_wpre = 0: split while staged (tiles 14-17)
-    assert all(not 14 <= o['tile_cfg'] <= 17 for o in wconvs) and any(18 <= o['tile_cfg'] <= 21 for o in wconvs)
-    nbytes_both = int(p.lib.sr3_plan_derived_bytes(p.handle))
-    p.set_option('gemm_wpre', 0)
-    nopre = [o for o in p.op_list(16) if o['kind'] == 50]
+    # the im2col SPLIT tiles split their weights while staging them by default (tiles 14-17); plan option gemm_wpre = 1 (round 6's form,
+    # measured slower again, kept as an A/B knob): they read them pre-split and in MFMA fragment order straight from the derived buffer
+    # (tiles 18-21), three bf16 planes = 6 bytes per weight of the res_convs, attention projections and Downsample convs with Cout > 64
+    assert all(not 18 <= o['tile_cfg'] <= 21 for o in wconvs) and any(14 <= o['tile_cfg'] <= 17 for o in wconvs)
     nbytes_nopre = int(p.lib.sr3_plan_derived_bytes(p.handle))
+    p.set_option('gemm_wpre', 1)
+    pre = [o for o in p.op_list(16) if o['kind'] == 50]
+    nbytes_both = int(p.lib.sr3_plan_derived_bytes(p.handle))
     nbytes_wsplit = nbytes_both - nbytes_nopre
-    n_w = sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in wconvs if 18 <= o['tile_cfg'] <= 21)
+    n_w = sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in pre if 18 <= o['tile_cfg'] <= 21)
     assert n_w > 0 and nbytes_wsplit == 6 * n_w           # (every such layer of this network has Cout, Cin multiples of 32: no padding)
     assert all((18 <= a['tile_cfg'] <= 21) == (14 <= b['tile_cfg'] <= 17) and a['tile_cfg'] in (b['tile_cfg'], b['tile_cfg'] + 4)
-               for a, b in zip(wconvs, nopre))
-    p.set_option('gemm_wpre', 1)
+               for a, b in zip(pre, wconvs))
     p.set_option('gemm_split', 0)
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_nopre      # nothing pre-split without the split tiles
     p.set_option('gemm_split', 1)
     assert int(p.lib.sr3_plan_derived_bytes(p.handle)) == nbytes_both
+    p.set_option('gemm_wpre', 0)
     assert p.op_list(16) == wops
+    nbytes_both, nbytes_wsplit = nbytes_nopre, 0
     p.set_option('wino_split', 0)                         # the exact-fp32 MFMA instantiation everywhere: same list, tile 11
     eops = p.op_list(16)
     assert len(eops) == len(wops)
@@ -229,7 +230,7 @@ def test_plan_launch_list_no_gpu():
         # default 1; reported as tile 16 = the split form of tile 3; 20 with pre-split weights under gemm_wpre = 1); the 9-tap
         # Downsample with Cout <= 64 stays on the fp32 MFMA
         if not halo:
-            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 20), o
+            assert o['tile_cfg'] == (2 if (o['ksize'] == 3 and o['cout'] <= 64) else 16), o
         if o['fused_res_conv_cin']:
             assert halo and not o['upsample']
     # 18 ResnetBlocks change their channel count: where block2's conv runs unsplit (the 128x128 and 64x64 levels) their
@@ -254,8 +255,8 @@ def test_plan_launch_list_no_gpu():
     p.set_option('gemm_split', 0)
     for a, b in zip(ops, p.op_list(16)):
         assert a['kind'] == b['kind'] and a['flops'] == b['flops']
-        if a['kind'] == 50 and 18 <= a['tile_cfg'] <= 21:
-            assert b['tile_cfg'] == a['tile_cfg'] - 17 == 3 and a['ksplit'] == b['ksplit'], (a, b)
+        if a['kind'] == 50 and 14 <= a['tile_cfg'] <= 17:
+            assert b['tile_cfg'] == a['tile_cfg'] - 13 == 3 and a['ksplit'] == b['ksplit'], (a, b)
         else:
             assert a['tile_cfg'] == b['tile_cfg'] and a['ksplit'] == b['ksplit']
     p.set_option('gemm_split', 1)
@@ -346,11 +347,11 @@ def test_round5_plan_options_no_gpu():
     for key in ('attn_split', 'wgrad_split'):
         assert p.set_option(key, 0) == 1 and p.op_list(16) == ops
         assert p.set_option(key, 1) == 0
-    # gemm_wpre (default 1 since round 6: the weights pre-split in MFMA fragment order, read straight from global memory): 20 <-> 16
-    assert sorted(set(o['tile_cfg'] for o in ops if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [20]
-    assert p.set_option('gemm_wpre', 0) == 1
-    assert sorted(set(o['tile_cfg'] for o in p.op_list(16) if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [16]
-    assert p.set_option('gemm_wpre', 1) == 0 and p.op_list(16) == ops
+    # gemm_wpre (default 0: the weights pre-split in MFMA fragment order, read straight from global memory, measured slower): 16 <-> 20
+    assert sorted(set(o['tile_cfg'] for o in ops if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [16]
+    assert p.set_option('gemm_wpre', 1) == 0
+    assert sorted(set(o['tile_cfg'] for o in p.op_list(16) if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [20]
+    assert p.set_option('gemm_wpre', 0) == 1 and p.op_list(16) == ops
     # wino2 (round 6): maps >= 16 x 16 between the two-workgroups-per-CU kernel (tile 13) and the 8-wave kernel (tile 12)
     assert any(o['tile_cfg'] == 13 for o in ops) and p.set_option('wino2', 0) == 1
     assert not any(o['tile_cfg'] == 13 for o in p.op_list(16)) and p.set_option('wino2', 1) == 0 and p.op_list(16) == ops

@@ -46,6 +46,31 @@ def test_loss_and_gradients_match_reference_autograd(name):
     assert not bad, 'gradient mismatch (rel err, key, |ref|): %s' % bad[:8]
 
 
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_training_step_is_bitwise_reproducible(name):
+    """Two evaluations of the same training step (same weights, batch, noise, dropout seed) give the same loss and the same
+    gradient arena BIT for bit: every reduction on the path has a fixed order -- since round 6 the attention backward's dK / dV too
+    (per-query-block slabs summed in order instead of fp32 atomics, attention_bwd.hip).  Both tiny networks carry attention blocks."""
+    m, g, sd = build_train(name)
+    d = G.dev()
+    un = m.netG.denoise_fn
+    assert any(o['kind'] == 60 for o in un.plan.op_list(2)), 'no attention op in this network: nothing to test'
+    data = {'HR': torch.from_numpy(g['loop/hr']).to(d), 'SR': torch.from_numpy(g['loop/sr']).to(d)}
+    z = torch.from_numpy(g['train/z']).to(d)
+    m.netG.train()
+    outs = []
+    for _ in range(3):
+        if DESCS[name]['variant'] == 'sr3':
+            loss = m.netG.p_losses(data, noise=z, gamma=torch.from_numpy(g['train/gamma']), drop_seed=1234)
+        else:
+            loss = m.netG.p_losses(data, noise=z, t=torch.from_numpy(g['train/t']).to(d), drop_seed=1234)
+        torch.cuda.synchronize()
+        outs.append((float(loss), un.grad_arena.clone()))
+    for l, ga in outs[1:]:
+        assert l == outs[0][0]
+        assert torch.equal(ga, outs[0][1]), 'gradient arenas differ between two runs of the same step: max |diff| %.3g' % float((ga - outs[0][1]).abs().max())
+
+
 @pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny', 'sr3_uncond'])
 def test_optimize_parameters_one_adam_step(name):
     """feed_data -> optimize_parameters (RNG draws patched to the recorded ones) -> weights after Adam."""
