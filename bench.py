@@ -515,7 +515,8 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
         dt = float(tt.item())
     ms = dt / steps * 1e3
     fl = 3.0 * m.netG.denoise_fn.plan.forward_flops(batch)
-    return {'roofline': train_roofline(cfg_name, ms),
+    dp_rec = dp_diagnostics(m, dist, rank, dev) if (dist and not STUB) else None
+    return {'roofline': train_roofline(cfg_name, ms), 'data_parallel': dp_rec,
             'metric': '%s training images/sec (p_losses + backward + Adam)' % c['title'], 'value': world * batch / (ms * 1e-3),
             'unit': 'images/s', 'steps_per_s': 1e3 / ms, 'ms_per_step': ms, 'steps': steps, 'warmup': warmup,
             'batch_per_gpu': batch, 'global_batch': batch * world, 'dropout': c['unet']['dropout'],
@@ -528,6 +529,33 @@ def train_leg(cfg_name, dist, world, rank, dev, batch, steps, warmup):
             'frac_of_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 'l_pix_last': m.get_current_log()['l_pix'],
             **({'stub': True, 'gradient_buckets_walked': m.buckets_walked,
                 'gradient_buckets_per_step': len(m.red.buckets) if m.red else 0} if STUB else {})}
+
+
+def dp_diagnostics(m, dist, rank, dev, extra_steps=3):
+    """After the timed training steps of an N-rank run, per rank: the world size the process group itself reports, the EXPOSED part of
+    the gradient all-reduce (event pair on the compute stream around its wait for the reducer's side stream, mean of a few extra
+    steps) and a checksum of the parameter arena -- the replicas must be bit-identical (same all-reduced gradient, same Adam step),
+    anything else raises.  Gathered to every rank; rank 0 puts the list into the record."""
+    import torch
+    un = m.netG.denoise_fn
+    red = getattr(un, '_reducer', None)
+    exposed = None
+    if red is not None and red.cuda:
+        red.measure_exposed = True
+        for _ in range(extra_steps):
+            m.optimize_parameters()
+        exposed = red.exposed_ms()
+        red.measure_exposed = False
+    bits = un.arena.data.view(torch.int32).to(torch.int64)
+    info = dict(rank=rank, nranks=dist.get_world_size(), backend=dist.get_backend(), device=str(dev),
+                exposed_allreduce_ms_per_step=exposed, buckets=None if red is None else len(red.buckets),
+                arena_checksum=[int(bits.sum().item()), int((bits * (torch.arange(bits.numel(), device=bits.device) % 8191 + 1)).sum().item())])
+    infos = [None] * dist.get_world_size()
+    dist.all_gather_object(infos, info)
+    same = all(i['arena_checksum'] == infos[0]['arena_checksum'] for i in infos)
+    if not same:
+        raise RuntimeError('data-parallel replicas diverged after the timed steps: %s' % [i['arena_checksum'] for i in infos])
+    return dict(replicas_bit_identical=True, ranks=infos)
 
 
 def train_roofline(cfg_name, ms_live):

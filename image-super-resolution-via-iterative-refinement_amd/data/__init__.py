@@ -45,13 +45,15 @@ class DeviceBatches(object):
 
     def __iter__(self):
         _, world = _dp()
-        from sr3_hip.dist import dp_active
-        if not (self.deal_waves and dp_active()):
+        from sr3_hip.dist import dp_active, val_chain_batch
+        chain = val_chain_batch() if self.deal_waves else 1
+        if not (self.deal_waves and (dp_active() or chain > 1)):
             yield from self._device_batches()
             return
-        # data-parallel validation: every rank walks ALL items in order, `world` at a time; the wave object lets
-        # DDPM.test run item k's reverse chain on rank k only and share the finished images (sr3_hip.dist.ValWave)
+        # validation: every rank walks ALL items in order, `world * chain` at a time; the wave object lets DDPM.test run the
+        # reverse chains once per wave -- a rank's items as one chain batch -- and share the finished images (sr3_hip.dist.ValWave)
         from sr3_hip.dist import ValWave
+        world = world if dp_active() else 1
         group = []
 
         def flush():
@@ -61,7 +63,7 @@ class DeviceBatches(object):
                 yield b
         for b in self._device_batches():
             group.append(b)
-            if len(group) == world:
+            if len(group) == world * chain:
                 yield from flush()
                 group = []
         if group:

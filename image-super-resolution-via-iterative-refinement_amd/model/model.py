@@ -68,9 +68,9 @@ class DDPM(BaseModel):
         self.netG.eval()
         with torch.no_grad():
             wave = self.data.get('_dp_wave') if isinstance(self.data, dict) else None
-            if wave is not None and _dist.dp_active():
-                # data parallel: the loader deals consecutive validation items over the ranks (sr3_hip.dist.ValWave);
-                # this item's chain ran on one rank, every rank gets the same image back
+            if wave is not None:
+                # the validation loader groups consecutive items into waves (sr3_hip.dist.ValWave): the chains of a wave run once,
+                # a rank's items as one batch (and, data parallel, dealt over the ranks); every caller gets its item's image back
                 self.SR = wave.result(self.netG, self.data['_dp_pos'], continous)
             else:
                 self.SR = self.netG.super_resolution(self.data['SR'], continous)

@@ -238,6 +238,8 @@ class GradReducer(object):
             self.events = [torch.cuda.Event() for _ in self.buckets]
             for ev in self.events:                 # materialise the hipEvent_t handles
                 ev.record(torch.cuda.current_stream(device))
+        self.measure_exposed = False       # bench.py: event pair on the compute stream around its wait for the side stream
+        self._exposed = []
 
     def mark_args(self):
         """(n, offsets array, event-handle array) for sr3_train_step."""
@@ -263,13 +265,30 @@ class GradReducer(object):
                     self.stream.wait_stream(cur)
                     for t in extra:
                         d.all_reduce(t, op=d.ReduceOp.SUM)
-            cur.wait_stream(self.stream)
+            if self.measure_exposed:               # e0: the backward is done; e1: the last collective too -> exposed communication
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.stream)
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+            else:
+                cur.wait_stream(self.stream)
         else:                                       # CPU tensors (gloo tests): same bucket walk, synchronous
             for lo, hi in self.buckets:
                 d.all_reduce(grad_arena[lo:hi], op=d.ReduceOp.SUM)
             if extra is not None:
                 for t in extra:
                     d.all_reduce(t, op=d.ReduceOp.SUM)
+
+
+    def exposed_ms(self):
+        """Mean time the compute stream waited for the side stream per step since measure_exposed was set (synchronises)."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize(self.device)
+        v = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(v) / len(v)
 
 
 # ---- validation / unconditional sampling: consecutive items dealt round-robin over the ranks ----------------
@@ -297,11 +316,23 @@ def _gather_ragged(own, world, tdist, dev):
     return [None if sh is None else p[:n].view(sh) for p, sh, n in zip(parts, shapes, numel)]
 
 
+def val_chain_batch():
+    """Validation items one reverse chain carries (ValWave): the reference's validation loader hands `infer.py` / `sr.py` ONE image per
+    call (data/__init__.py:18, batch_size = 1), and a batch-1 chain is launch-bound (bench.py: other_configs.sr3_16_128_b1) -- so
+    consecutive items are run as one batch and handed back one by one.  SR3_VAL_CHAIN_BATCH overrides (1 = the reference's one
+    chain per image)."""
+    v = os.environ.get('SR3_VAL_CHAIN_BATCH')
+    return max(1, int(v)) if v not in (None, '') else 16
+
+
 class ValWave(object):
-    """Up to `world` consecutive validation batches.  Every rank iterates ALL of them in order (so the caller's idx,
-    file names and PSNR average are those of a single process -- sr.py:112-141, infer.py:64-90), but the reverse chain
-    of item k runs only on rank k, once, when the first item of the wave is tested; the finished images are all-gathered
-    and `DDPM.test` hands item k's to the caller when it gets there.  Rides in the batch dict under '_dp_wave'."""
+    """Up to `world * chain` consecutive validation batches.  Every rank iterates ALL of them in order (so the caller's idx,
+    file names and PSNR average are those of a single process -- sr.py:112-141, infer.py:64-90), but the reverse chains run
+    once, when the first item of the wave is tested: the items are dealt to the ranks in contiguous runs, a rank runs its items
+    of equal shape as ONE chain batch (round 6), the finished images are all-gathered and `DDPM.test` hands item k's to the
+    caller when it gets there.  Rides in the batch dict under '_dp_wave'.  With one process the same object batches consecutive
+    items into one chain.  The noise of a batched chain is one draw for the whole batch from the torch RNG: each image is a
+    sample of the same distribution as its batch-1 chain's, not the same realisation (the reference does not seed)."""
 
     def __init__(self, conds):
         self.conds = conds            # list of (B, 3, H, W) conditioning tensors ('SR' entries), one per item
@@ -311,18 +342,51 @@ class ValWave(object):
     def to(self, *args, **kwargs):    # feed_data moves every dict entry with .to(device)
         return self
 
+    @staticmethod
+    def _run_items(netG, conds, continous):
+        """The chains of `conds` (a list), equal shapes batched: returns one result per item, in the form
+        `super_resolution(cond, continous)` has for that item alone."""
+        out = [None] * len(conds)
+        groups = {}
+        for i, c in enumerate(conds):
+            groups.setdefault(tuple(c.shape), []).append(i)
+        for shape, idx in groups.items():
+            if len(idx) == 1:
+                out[idx[0]] = netG.super_resolution(conds[idx[0]], continous)
+                continue
+            b = [conds[i].shape[0] for i in idx]
+            ret = netG.super_resolution(torch.cat([conds[i] for i in idx], dim=0), True)     # (snapshots * sum(b), C, H, W)
+            n = sum(b)
+            snaps = ret.view(ret.shape[0] // n, n, *ret.shape[1:])
+            lo = 0
+            for i, bi in zip(idx, b):
+                own = snaps[:, lo:lo + bi]
+                lo += bi
+                # continous: the snapshots of this item stacked along dim 0; else the reference's `ret_img[-1]`: the LAST image
+                out[i] = own.reshape(-1, *ret.shape[1:]).clone() if continous else own[-1, -1].clone()
+        return out
+
     def run(self, netG, continous):
-        import torch.distributed as tdist
         rank, world, _ = dp_info()
         n = len(self.conds)
-        own = None
-        if rank < n:
-            own = netG.super_resolution(self.conds[rank], continous)
-        # items may differ in shape (an inference set with mixed resolutions) and a ragged last wave leaves ranks without
-        # one: shapes are gathered first, payloads padded to the largest
-        dev = own.device if own is not None else self.conds[0].device
-        parts = _gather_ragged(own, world, tdist, dev)
-        self.results = parts[:n]
+        if not dp_active():
+            self.results = self._run_items(netG, self.conds, continous)
+            self.continous = continous
+            return
+        import torch.distributed as tdist
+        per = -(-n // world)                       # contiguous runs: rank r owns items [r * per, (r + 1) * per)
+        mine = list(range(rank * per, min((rank + 1) * per, n)))
+        own = self._run_items(netG, [self.conds[i] for i in mine], continous) if mine else []
+        # items may differ in shape (an inference set with mixed resolutions) and a ragged last wave leaves ranks with fewer
+        # items: per slot, shapes are gathered first, payloads padded to the largest
+        dev = own[0].device if own else self.conds[0].device
+        results = [None] * n
+        for j in range(per):
+            parts = _gather_ragged(own[j] if j < len(own) else None, world, tdist, dev)
+            for r in range(world):
+                if r * per + j < n:
+                    results[r * per + j] = parts[r]
+        self.results = results
         self.continous = continous
 
     def result(self, netG, pos, continous):

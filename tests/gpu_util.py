@@ -77,10 +77,10 @@ def wino_expected_refusal(B, Cin, H, W, ups, tile, ksplit, k=3, stride=1):
     if ksplit == 0:
         return None
     chunks = -(-Cin // 16)
+    if -(-chunks // ksplit) > (16 if nb4 else 64):          # (checked first by conv3x3_wino_forward)
+        return 'per K split'
     if nb4 and ksplit < 2:
         return 'split-K only'
-    if -(-chunks // ksplit) > (16 if nb4 else 64):
-        return 'per K split'
     if ksplit > 1 and (ksplit - 1) * -(-chunks // ksplit) >= chunks:
         return 'empty split'
     return None

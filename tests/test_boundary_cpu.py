@@ -142,15 +142,16 @@ def test_bench_configs_are_the_reference_json_configs(name):
 
 def test_committed_profile_summaries_cover_the_kernels_bench_reports():
     """bench.py's `roofline.traffic` / `sq_counters` come from the committed rocprofv3 counter summaries of the round, looked up by
-    the exact symbol of the dominant kernel: both plans the bench line reports (default: the split Winograd instantiation;
-    `exact_fp32`: the fp32-MFMA one) must be in them, with sane values, or those fields silently turn null."""
+    the exact symbol of the dominant kernel: both plans the bench line reports (default: the two-workgroups-per-CU split Winograd
+    kernel of round 6; `exact_fp32`: the 8-wave kernel's fp32-MFMA instantiation) must be in them, with sane values, or those
+    fields silently turn null."""
     sys.path.insert(0, ROOT)
     import bench
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_hbm_traffic.json')) as f:
         traffic = json.load(f)
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_sq_counters.json')) as f:
         sq = json.load(f)
-    for sym in ('sr3::k_conv3x3_wino<0, false, false, true>', 'sr3::k_conv3x3_wino<0, false, false, false>',
+    for sym in ('sr3::k_conv3x3_wino2<0>', 'sr3::k_conv3x3_wino<0, false, false, false>',
                 'sr3::k_conv_igemm<64, 64, 1, 1>', 'sr3::k_conv_igemm<64, 64, 1, 0>',
                 'sr3::k_conv3x3_wino<0, false, true, true>', 'sr3::k_attention_v2<2, 2, true>'):
         assert 5e6 < traffic[sym]['hbm_bytes_per_launch'] < 1e9, (sym, traffic.get(sym))
@@ -158,7 +159,7 @@ def test_committed_profile_summaries_cover_the_kernels_bench_reports():
     # the stats file the bench line's avg launch time must agree with
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_bench_kernel_stats.csv')) as f:
         head = f.read(4000)
-    assert 'k_conv3x3_wino<0, false, false, true>' in head
+    assert 'k_conv3x3_wino2<0>' in head
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_bench.json')) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',

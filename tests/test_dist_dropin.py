@@ -25,6 +25,7 @@ def _free_port():
 
 def _launch(world, out_dir, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env['SR3_VAL_CHAIN_BATCH'] = '1'         # one chain per validation image, as the reference: these tests count chains per rank
     env.update(extra_env or {})
     worker = os.path.join(ROOT, 'tests', 'dp_dropin_worker.py')
     if world == 1:

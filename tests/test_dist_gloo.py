@@ -250,3 +250,29 @@ def test_validation_wave_mixed_shapes_and_ragged_wave_two_ranks(shapes):
             cond = torch.arange(3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k
             assert torch.equal(out[True][k], torch.cat([cond, cond * 3 + 1], 0))
             assert torch.equal(out[False][k], (cond * 3 + 1)[-1])
+
+
+def test_validation_wave_batches_equal_shapes_single_process():
+    """ValWave without a process group (plain `infer.py`): consecutive items of equal shape run as ONE chain batch, odd shapes on
+    their own, and every item gets back exactly what its own batch-1 call would return -- for both `continous` flavours (the
+    reference's continous = False returns `ret_img[-1]`: the last image only)."""
+    sys.path.insert(0, PKG)
+    from sr3_hip import dist as D
+
+    class Net(object):
+        calls = []
+
+        def super_resolution(self, cond, continous):                 # two "snapshots": the conditioning, then the result
+            Net.calls.append(tuple(cond.shape))
+            img = cond * 3 + 1
+            return torch.cat([cond, img], 0) if continous else img[-1]
+    shapes = [(4, 4), (4, 4), (8, 6), (4, 4), (2, 2)]
+    conds = [torch.arange(3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k for k, (h, w) in enumerate(shapes)]
+    for continous in (True, False):
+        Net.calls = []
+        wave = D.ValWave(conds)
+        got = [wave.result(Net(), pos, continous) for pos in range(len(conds))]
+        assert sorted(Net.calls) == sorted([(3, 3, 4, 4), (1, 3, 8, 6), (1, 3, 2, 2)]), Net.calls
+        for k, c in enumerate(conds):
+            want = torch.cat([c, c * 3 + 1], 0) if continous else (c * 3 + 1)[-1]
+            assert torch.equal(got[k], want), (continous, k)

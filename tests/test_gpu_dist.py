@@ -116,6 +116,7 @@ def _val_main(rank, world, port, root, ret):
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                           WORLD_SIZE=str(world), SR3_DP='force')
     import torch.distributed as dist
+    os.environ['SR3_VAL_CHAIN_BATCH'] = '1'          # one chain per image, as the reference: this test is about the dealing over ranks
     try:
         import data as Data
         import model as Model
@@ -173,3 +174,138 @@ def test_validation_waves_through_the_dropin(world, tmp_path):
         assert not ref[0]['active'] and [w[0] for w in ref[0]['waves']] == [False] * n_items
         for k in range(n_items):
             assert torch.equal(ref[0]['outs'][k], ret[0]['outs'][k])
+
+
+class _SlowCollective(object):
+    """Stand-in for torch.distributed inside GradReducer: `all_reduce` occupies the stream it is called on (the reducer's side stream)
+    for a fixed time and then doubles the tensor in-stream -- a marker that tells, element by element, whether a bucket's collective
+    ran AFTER its gradients were written and BEFORE anything downstream of the reducer read them."""
+    class ReduceOp(object):
+        SUM = 0
+
+    def __init__(self, cycles):
+        self.cycles = cycles
+        self.calls = 0
+
+    def all_reduce(self, t, op=None):
+        if self.cycles:
+            torch.cuda._sleep(self.cycles)
+        t.mul_(2.0)
+        self.calls += 1
+
+
+@pytest.mark.timeout(600)
+def test_bucket_reduce_overlaps_the_backward_and_gates_what_follows():
+    """The side-stream / event logic of `GradReducer` on the REAL training step (SR3 16->128, batch 16, 12+ buckets) with a collective
+    that takes a known time (two RCCL ranks cannot share the one GPU of this box): (1) every bucket is reduced exactly once, after
+    its gradient-ready event (the doubled gradient equals 2 x the plain step's, bit for bit); (2) what is enqueued after
+    `reduce()` on the compute stream -- where Adam goes -- sees all buckets reduced; (3) the bucket collectives run BESIDE the rest
+    of the backward: the step grows by far less than the time the side stream was occupied (the failure DESIGN.md 3.3 names:
+    event waits serialising behind the compute stream)."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    import model as Model
+    from sr3_hip.dist import GradReducer
+    d = torch.device('cuda', 0)
+    torch.manual_seed(5)
+    m = Model.create_model(bench.config_opt('sr3_16_128', phase='train'))
+    un = m.netG.denoise_fn
+    un.train()
+    B = 16
+    g = torch.Generator().manual_seed(1)
+    hr = (torch.rand(B, 3, 128, 128, generator=g) * 2 - 1).to(d)
+    sr = (torch.rand(B, 3, 128, 128, generator=g) * 2 - 1).to(d)
+    z = torch.randn(B, 3, 128, 128, generator=g).to(d)
+    gamma = (torch.rand(B, generator=g) * 0.8 + 0.1).to(d)
+    ca, cb = gamma.clone(), (1 - gamma ** 2).sqrt()
+    scale = 1.0 / hr.numel()
+
+    def step(red):
+        loss = torch.zeros(1, device=d)
+        marks = red.mark_args() if red else (0, None, None)
+        un._engine_train_step(hr, sr, z, ca, cb, gamma, None, scale, 0.2, 99, marks, loss)
+        if red:
+            red.reduce(un.grad_arena, extra=[loss])
+        return un.grad_arena.clone(), loss.clone()      # enqueued on the compute stream, where the optimizer step would be
+
+    def timed(red, n=4):
+        step(red)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(red)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    un.grad_arena = torch.zeros_like(un.arena.data)
+    g0, l0 = step(None)
+    torch.cuda.synchronize()
+    # calibrate the sleep: cycles for ~2 ms
+    torch.cuda._sleep(1000000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.cuda._sleep(20000000)
+    torch.cuda.synchronize()
+    cyc_per_ms = 20000000 / ((time.perf_counter() - t0) * 1e3)
+    fast, slow = _SlowCollective(0), _SlowCollective(int(2.0 * cyc_per_ms))
+    red_fast = GradReducer(un.arena.numel(), d, fast)
+    red_slow = GradReducer(un.arena.numel(), d, slow)
+    nb = len(red_slow.buckets)
+    assert nb >= 12
+    g1, l1 = step(red_slow)
+    torch.cuda.synchronize()
+    assert slow.calls == nb + 1                                     # every bucket once + the loss scalar
+    assert torch.equal(g1, g0 * 2.0) and torch.equal(l1, l0 * 2.0), 'a bucket was reduced before its gradients were ready, or read before it was reduced'
+    t_plain, t_fast, t_slow = timed(None), timed(red_fast), timed(red_slow)
+    occupied = nb * 2.0
+    print('training step at batch %d: plain %.1f ms, %d-bucket reducer with a free collective %.1f ms, with %.1f ms collectives (%.0f ms on the '
+          'side stream) %.1f ms' % (B, t_plain, nb, t_fast, 2.0, occupied, t_slow))
+    assert t_slow - t_fast < 0.5 * occupied, (t_plain, t_fast, t_slow, occupied)
+
+
+@pytest.mark.timeout(600)
+def test_validation_items_batched_into_one_chain_single_process(tmp_path, monkeypatch):
+    """The reference's validation loop feeds `DDPM.test` one image per call (data/__init__.py:18; infer.py:64-90); the drop-in's
+    loader groups consecutive items into a wave whose chains run as ONE batch (sr3_hip.dist.ValWave, round 6).  Five items, chain
+    batch 4: the loop sees every item in order with the reference's shapes, the first wave is exactly the batched
+    `super_resolution` call under the same seed, and the reverse loop ran twice (4 + 1 items), not five times."""
+    sys.path.insert(0, PKG)
+    from test_oracle_io import _write_triplets
+    import data as Data
+    import model as Model
+    root = str(tmp_path / 'ds')
+    _write_triplets(root, 5, l=4, r=16)
+    monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', '4')
+    dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
+    loader = Data.create_dataloader(Data.create_dataset(dopt, 'val'), dopt, 'val')
+    opt = opt_for(NAME, phase='val', gpu=True)
+    m = Model.create_model(opt)
+    _, sd = load_golden(NAME)
+    m.netG.load_state_dict(sd, strict=True)
+    m.netG.show_progress = False
+    m.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+    calls = []
+    orig = m.netG.super_resolution
+    m.netG.super_resolution = lambda x, continous=False: (calls.append(tuple(x.shape)), orig(x, continous))[1]
+    outs_c, outs_f, conds = [], [], []
+    for continous, outs in ((True, outs_c), (False, outs_f)):
+        for idx, val_data in enumerate(loader):
+            m.feed_data(val_data)
+            if val_data['_dp_pos'] == 0:
+                torch.manual_seed(900 + idx)
+            m.test(continous=continous)
+            outs.append(m.get_current_visuals(need_LR=False)['SR'].clone())
+            if continous:
+                conds.append(val_data['SR'].clone())
+    assert calls == [(4, 3, 16, 16), (1, 3, 16, 16)] * 2, calls
+    n_snap = outs_c[4].shape[0]                       # the batch-1 chain of the last wave: the reference's own shapes
+    assert all(o.shape == (n_snap, 3, 16, 16) and bool(torch.isfinite(o).all()) for o in outs_c)
+    assert all(o.shape == (3, 16, 16) for o in outs_f)
+    torch.manual_seed(900)
+    ref = orig(torch.cat(conds[:4], 0).to(m.device), True).cpu()
+    ref = ref.view(n_snap, 4, 3, 16, 16)
+    for k in range(4):
+        assert torch.equal(outs_c[k], ref[:, k]), k
+        assert torch.equal(outs_f[k], ref[-1, k]), k                   # (same seed: the continous = False pass repeats the chain)
+        assert torch.equal(outs_c[k][0], conds[k][0].cpu())            # snapshot 0 is the conditioning image (sr3 diffusion.py:180-187)

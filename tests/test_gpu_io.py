@@ -162,7 +162,9 @@ def test_device_batches_feed_the_model(tmp_path):
     vopt = dict(opt, mode='LRHR')
     vds = Data.create_dataset(vopt, 'val')
     vb = next(iter(Data.create_dataloader(vds, vopt, 'val')))
-    assert set(vb) == {'HR', 'SR', 'LR', 'Index'} and tuple(vb['LR'].shape) == (1, 3, 16, 16)
+    # (the two underscore entries are the validation wave the loader attaches, sr3_hip.dist.ValWave: DDPM.test runs the chains of
+    #  consecutive items as one batch; SR3_VAL_CHAIN_BATCH=1 leaves the reference's dict as it is)
+    assert set(vb) == {'HR', 'SR', 'LR', 'Index', '_dp_wave', '_dp_pos'} and tuple(vb['LR'].shape) == (1, 3, 16, 16)
     img = np.asarray(Image.open(os.path.join(root, 'lr_16', '00000.png')).convert('RGB'))
     assert np.array_equal(vb['LR'][0].cpu().numpy(), O.transform_augment([img], 'val', (-1, 1))[0])
 
