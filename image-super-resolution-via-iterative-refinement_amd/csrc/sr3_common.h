@@ -170,7 +170,7 @@ struct ConvParams {
   int wino_split;      // 1: the filters are the 3 x bf16 split form and the kernel's SPLIT instantiation runs (tile_cfg 12 at the ABI);
                        // 2: the same filters on the two-workgroups-per-CU kernel of conv3x3_wino2.hip (tile_cfg 13; 8 x 16 pixel tile)
   int igemm_split;     // im2col kernel (tile_cfg 1-4; 1x1 and stride-2 convs): 1 = its 3 x bf16 split instantiation (tile_cfg 14-17 at the ABI)
-  int wgrad_split;     // weight gradient (wgrad.hip): 1 = the one-tap-per-workgroup kernel's 3 x bf16 split instantiation for every layer
+  int wgrad_split;     // weight gradient (wgrad.hip): 1 = the one-tap-per-workgroup kernel's 3 x bf16 split instantiation for the layers with > 64 channels on both sides
   const void* w_split; // igemm_split: the weights pre-split into bf16 planes by igemm_split_weights (tile_cfg 18-21 at the ABI; a plan
                        // keeps them in its derived buffer); null: the kernel splits the weights while it stages them
 };

@@ -10,6 +10,8 @@
 // range is split over gridDim.z and the partial slabs are summed by a deterministic reduce kernel.
 #include <algorithm>
 
+#include <string.h>
+
 #include "sr3_common.h"
 #include "train.h"
 
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const ConvParams p, const
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The same GEMM on v_mfma_f32_32x32x16_bf16 with 3-way split fp32 operands (round 5; plan option wgrad_split, default off until
-// its evidence is whole): six bf16 products per fp32 product, fp32 accumulation -- the arithmetic of the split conv kernels.
+// The same GEMM on v_mfma_f32_32x32x16_bf16 with 3-way split fp32 operands (round 5; plan option wgrad_split, default ON, used for
+// the layers with more than 64 channels on both sides): six bf16 products per fp32 product, fp32 accumulation -- the arithmetic of the split conv kernels.
 // The contraction runs over PIXELS, which are the rows of both NHWC operands, while a bf16 MFMA operand wants 8 consecutive k per
 // lane: the staging step transposes.  A unit of staging = 8 consecutive pixels (one k-half of a 16-pixel k-step) x 4 channels:
 // eight 16-byte loads, per channel one split3x8 of the eight pixel values, three 16-byte LDS writes into
@@ -626,3 +628,33 @@ int conv_wgrad(const WgradParams& p, hipStream_t st) {
 }
 
 }  // namespace sr3
+
+// ---- per-op entry (include/sr3_mi355x.h): the weight gradient of one convolution, for op-level tests of every kernel of this file ----
+namespace {
+void wgrad_fill(sr3::ConvParams& c, const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups, int stride, int ksize,
+                int Cout, const float* ss, int act, int split) {
+  memset(&c, 0, sizeof(c));
+  c.src0 = src0; c.src1 = src1; c.C0 = C0; c.C1 = src1 ? C1 : 0; c.B = B; c.Hs = Hs; c.Ws = Ws; c.ups = ups; c.stride = stride; c.ksize = ksize;
+  const int pad = ksize / 2;
+  c.Ho = ((Hs << ups) + 2 * pad - ksize) / stride + 1;
+  c.Wo = ((Ws << ups) + 2 * pad - ksize) / stride + 1;
+  c.Cout = Cout; c.ss = ss; c.act = act; c.ksplit = 1; c.wgrad_split = split;
+}
+}  // namespace
+extern "C" size_t sr3_conv_wgrad_scratch_bytes(int B, int Hs, int Ws, int ups, int stride, int ksize, int C0, int C1, int Cout, int split) {
+  sr3::ConvParams c;
+  wgrad_fill(c, nullptr, C0, C1 ? reinterpret_cast<const float*>(1) : nullptr, C1, B, Hs, Ws, ups, stride, ksize, Cout, nullptr, 0, split);
+  return sr3::wgrad_slab_bytes(c, nullptr);
+}
+extern "C" int sr3_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups, int stride, int ksize,
+                                  int Cout, const float* ss, int act, const float* dy, float* dw_ohwi, int split, void* scratch,
+                                  size_t scratch_bytes, void* stream) {
+  if (!src0 || !dy || !dw_ohwi) { sr3::set_error("null argument"); return SR3_E_BADARG; }
+  if ((ksize != 1 && ksize != 3) || (stride != 1 && stride != 2) || (ups != 0 && ups != 1)) { sr3::set_error("wgrad: ksize 1 | 3, stride 1 | 2, ups 0 | 1"); return SR3_E_UNSUPPORTED; }
+  sr3::WgradParams wp;
+  wgrad_fill(wp.c, src0, C0, src1, C1, B, Hs, Ws, ups, stride, ksize, Cout, ss, act, split);
+  wp.dy = dy; wp.dw = dw_ohwi; wp.slabs = static_cast<float*>(scratch);
+  const size_t need = sr3::wgrad_slab_bytes(wp.c, &wp.msplit);
+  if (wp.msplit > 1 && (!scratch || scratch_bytes < need)) { sr3::set_error("wgrad: scratch too small (%zu < %zu)", scratch_bytes, need); return SR3_E_NOMEM; }
+  return sr3::conv_wgrad(wp, static_cast<hipStream_t>(stream));
+}

@@ -48,6 +48,8 @@ SIGNATURES = {
     'sr3_eval_scratch_bytes': (_Z, [_I, _I, _I, _I]),
     'sr3_eval_psnr_ssim_f32': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _P, _Z, _P, _P, _P]),
     'sr3_attention_bwd_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'sr3_conv_wgrad_scratch_bytes': (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    'sr3_conv_wgrad_f32': (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     'sr3_attention_bwd_scratch_bytes': (_Z, [_I, _I, _I]),
     'sr3_attention_bwd_ex_f32': (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _Z, _P]),
     'sr3_resize_scratch_bytes': (_Z, [_I, _I, _I, _I, _I, _I]),

@@ -95,7 +95,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "gemm_split", "gemm_tile", "wino4", "loss_l2"};
+ * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm_wpre", "gemm_tile", "wgrad_split", "attn_split", "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
  *   split instantiation: every fp32 operand as x = h + m + l (three bf16 terms, each residual exact in fp32), every product as
@@ -110,15 +110,18 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   kernel -- how profiles/r04f_gemm_split_sweep.txt timed the tiles inside the forward.
  * wino_split8 (default 1, round 5): the four-image tile of the 8x8 maps on its 3 x bf16 split instantiation too (no dropout form:
  *   a training forward's dropout convs on 8x8 maps keep the fp32 MFMA).
- * gemm_wpre (default 0): the im2col split tiles read their weights pre-split from the derived buffer (tiles 18-21) instead of
- *   splitting them while staging; measured slower in both layouts tried (profiles/r05b_*), kept as an A/B knob.
- * wgrad_split (default 1, round 5; training): weight gradients of every layer with more than 64 input and output channels on
+ * wino2 (default 1, round 6): the wino_split convolutions of the one-image tile without dropout -- every 3x3 stride-1 convolution on
+ *   maps >= 16 wide in an inference plan, block1 / Upsample convs and the data gradients in a training plan -- run as TWO independent
+ *   four-wave workgroups per CU on an 8 x 16 pixel tile (conv3x3_wino2.hip; reported as tile 13): same arithmetic and derived filters,
+ *   a wave owns one transform column and all four rows.  0: the 8-wave kernel of conv3x3_wino.hip everywhere (tile 12).
+ * gemm_wpre (default 0): the im2col split tiles read their weights pre-split AND in MFMA fragment order straight from the derived
+ *   buffer (tiles 18-21; round 6's form, no LDS staging of the weights) instead of splitting them while staging (14-17, what a plan
+ *   runs); measured slower in every layout tried (profiles/r05c_*, profiles/r06_gemm_wpre_fragment_major.txt), kept as an A/B knob.
+ * wgrad_split (default 1, round 5; training): weight gradients of the layers with more than 64 input AND output channels on
  *   v_mfma_f32_32x32x16_bf16 with 3-way split operands (wgrad.hip), gated by the batch-64 gradient tests against float64 autograd;
  *   0: the fp32-MFMA weight-gradient kernels.  No rebuild of the plan.
  * attn_split (default 1, round 5): SelfAttention's two contractions (Q K^T, P V) on the 3 x bf16 split instantiation of the
  *   staging-free kernel, gated against float64 like the convolutions; 0: v_mfma_f32_32x32x2_f32.  No rebuild of the plan.
- * wino4 (default 0, experimental; needs a library built with -DSR3_EXPERIMENTS, refused otherwise): wino_split convolutions on the
- *   four-wave, 512-register kernel (conv3x3_wino4.hip).
  * loss_l2 (default 0): sr3_train_step uses nn.MSELoss(reduction='sum') instead of nn.L1Loss(reduction='sum')
  *   (GaussianDiffusion(loss_type='l2'), model/sr3_modules/diffusion.py:84-90).
  * split_bf16 (default 0, experimental; needs -DSR3_EXPERIMENTS, refused otherwise): run the halo-tile 3x3 convolutions of the inference plan on
@@ -264,11 +267,14 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * weights OHWI.  tile_cfg/ksplit 0 = auto (direct kernels only); tile_cfg 11 = Winograd F(2x2,3x3) (3x3 stride 1, H and W
  * multiples of 16, or 8x8 maps with B % 4 == 0 -- four images per workgroup tile, split-K only; the transformed filters are
  * derived into `scratch` by this entry point); tile_cfg 12 = the same kernel's 3 x bf16 split instantiation (one-image tile
- * only; what plan option wino_split selects), 13 = its four-wave experimental form (plan option wino4); tile_cfg 1-4 = the
+ * only, and the four-image tile of the 8x8 maps; what plan option wino_split selects there), 13 = the same arithmetic as two
+ * four-wave workgroups per CU on an 8 x 16 pixel tile (conv3x3_wino2.hip; W >= 16 and a multiple of 16, H a multiple of 8, no
+ * dropout form; what plan option wino2 -- default on -- selects on maps >= 16 wide); tile_cfg 1-4 = the
  * im2col kernel's 128x128 / 128x64 / 64x64 / 64x128 tiles on the exact-fp32 MFMA, 14-17 = the same tiles on the 3 x bf16 split
- * instantiation with both operands split while they are staged, 18-21 = the same with the weights pre-split into bf16 planes
- * (what plan option gemm_split selects: a plan keeps the planes in its derived buffer; this entry point derives them into
- * `scratch`; results are bit-identical to 14-17).
+ * instantiation with both operands split while they are staged (what plan option gemm_split selects: what a plan runs), 18-21 =
+ * the same with the weights pre-split into bf16 planes in MFMA fragment order and read straight from global memory (plan option
+ * gemm_wpre, default off: a plan keeps the planes in its derived buffer; this entry point derives them into `scratch`; results
+ * are bit-identical to 14-17).
  * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-21), sized by
  * sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
@@ -326,6 +332,16 @@ int sr3_attention_bwd_f32(const float* qkv, const float* dout, const float* out_
 size_t sr3_attention_bwd_scratch_bytes(int B, int N, int C);
 int sr3_attention_bwd_ex_f32(const float* qkv, const float* dout, const float* out_fwd, int B, int N, int C, float* dqkv,
                              void* scratch, size_t scratch_bytes, void* stream);
+/* Weight gradient of one convolution (autograd of nn.Conv2d inside `l_pix.backward()`, model/model.py:50-54), per op -- what
+ * sr3_train_step runs per layer: dw[n][tap][c] = sum over output pixels of dy[m][n] * a_tap[m][c], with a = the convolution's
+ * (virtual concat, optionally x2-upsampled, optionally GroupNorm-affine / SiLU-activated: act, ss as in sr3_conv_f32) input.
+ * dy NHWC [B, Ho, Wo, Cout]; dw OHWI [Cout][ksize^2][C0 + C1], overwritten.  split != 0: the 3 x bf16 split kernel where it applies
+ * (more than 64 channels on both sides; plan option wgrad_split), else the fp32-MFMA kernels.  scratch: the per-pixel-range slabs
+ * (sr3_conv_wgrad_scratch_bytes), summed in double in a fixed order. */
+size_t sr3_conv_wgrad_scratch_bytes(int B, int Hs, int Ws, int ups, int stride, int ksize, int C0, int C1, int Cout, int split);
+int sr3_conv_wgrad_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups, int stride, int ksize,
+                       int Cout, const float* ss, int act, const float* dy, float* dw_ohwi, int split, void* scratch,
+                       size_t scratch_bytes, void* stream);
 /* noise-level / timestep embedding + MLP + all FiLM rows (unet.py:18-50,179-184): see sr3_common.h */
 int sr3_film_embed_f32(int variant, int B, int inner, const float* level, const int64_t* timestep,
                        const float* freq, const float* w1, const float* b1, const float* w2, const float* b2,

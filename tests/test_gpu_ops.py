@@ -638,6 +638,67 @@ def test_attention_backward(B, N, C):
             L.check(lib.sr3_attention_bwd_f32(L.ptr(qd), L.ptr(gd), None, B, N, C, L.ptr(dq), G.stream()))
 
 
+WGRAD_CASES = [
+    # name, B, C0, C1, H, W, Cout, k, stride, ups, act     (what sr3_train_step meets, and the odd shapes it does not)
+    ('w3_128to128_16', 4, 128, 0, 16, 16, 128, 3, 1, 0, 0),
+    ('w3_concat192to320_act', 2, 128, 64, 16, 16, 320, 3, 1, 0, 2),
+    ('w1_concat384to128', 2, 256, 128, 32, 32, 128, 1, 1, 0, 0),
+    ('w3_s2_128to128', 2, 128, 0, 32, 32, 128, 3, 2, 0, 0),
+    ('w3_up_256to256', 2, 256, 0, 8, 8, 256, 3, 1, 1, 0),
+    ('w3_ragged_M100_136to200_act', 1, 136, 0, 10, 10, 200, 3, 1, 0, 1),
+    ('w3_64to64_128', 2, 64, 0, 64, 64, 64, 3, 1, 0, 0),
+    ('w1_96to64', 2, 96, 0, 16, 16, 64, 1, 1, 0, 2),
+]
+
+
+@pytest.mark.parametrize('split', [0, 1])
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_weight_gradient_per_op(case, split):
+    """Every weight-gradient kernel of wgrad.hip through its per-op entry against float64 autograd of F.conv2d: the 3 x bf16 split
+    kernel (layers with more than 64 channels on both sides, `split` = 1) on concat inputs, channel counts that are not multiples of
+    128, pixel counts that are not multiples of 32, stride 2, the x2-upsampled input and its fused activation form; the 9-tap and
+    generic fp32-MFMA kernels on the rest.  Normwise 2e-6 (fp32 class); split not worse than 1.25 x the fp32 kernel where both run."""
+    import torch.nn.functional as F
+    name, B, C0, C1, H, W, Cout, k, stride, ups, act = case
+    lib = L.load()
+    d = G.dev()
+    Cin = C0 + C1
+    x0 = _rand(B, C0, H, W, seed=31)
+    x1 = _rand(B, C1, H, W, seed=32) if C1 else None
+    ss = torch.stack([_rand(B, Cin, seed=33) * 0.3 + 1.0, _rand(B, Cin, seed=34) * 0.3], dim=2).contiguous() if act else None
+    pad = k // 2
+    Ho = ((H << ups) + 2 * pad - k) // stride + 1
+    Wo = ((W << ups) + 2 * pad - k) // stride + 1
+    dy = _rand(B, Cout, Ho, Wo, seed=35)
+    a = (x0 if x1 is None else torch.cat([x0, x1], 1)).double()
+    if act:
+        a = a * ss[:, :, 0].double()[:, :, None, None] + ss[:, :, 1].double()[:, :, None, None]
+        if act == 2:
+            a = a * torch.sigmoid(a)
+    if ups:
+        a = F.interpolate(a, scale_factor=2, mode='nearest')
+    w = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(a, w, None, stride=stride, padding=pad).backward(dy.double())
+    ref = w.grad
+    g = lambda t: None if t is None else t.to(d)
+
+    def run(sp):
+        nb = int(lib.sr3_conv_wgrad_scratch_bytes(B, H, W, ups, stride, k, C0, C1, Cout, sp))
+        scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
+        dw = torch.full((Cout, k * k, Cin), float('nan'), device=d)
+        L.check(lib.sr3_conv_wgrad_f32(L.ptr(g(G.nhwc(x0))), C0, L.ptr(None if x1 is None else g(G.nhwc(x1))), C1, B, H, W, ups, stride, k, Cout,
+                                       L.ptr(g(ss)), act, L.ptr(g(G.nhwc(dy))), L.ptr(dw), sp, L.ptr(scratch), nb, G.stream()))
+        torch.cuda.synchronize()
+        got = dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2).double()
+        return (got - ref).norm().item() / ref.norm().item()
+    e = run(split)
+    assert e < 2e-6, (name, split, e)
+    if split and Cout > 64 and Cin > 64:
+        e0 = run(0)
+        print('%s: weight-gradient rel err vs float64: split %.2e, fp32 MFMA %.2e' % (name, e, e0))
+        assert e <= 1.25 * e0 + 1e-8, (e, e0)
+
+
 @pytest.mark.parametrize('variant', [0, 1])
 def test_film_embed(variant):
     lib = L.load()

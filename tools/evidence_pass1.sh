@@ -21,6 +21,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_I
 python tools/pmc_sq.py $OUT/train_sq $OUT/${TAG}_train >> $OUT/pmc.log 2>&1
 python tools/torch_baseline_probe.py --config sr3_16_128 --batch 16 --steps 3 > $OUT/torch_warm.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/torch_stats -o torch -- python tools/torch_baseline_probe.py --config sr3_16_128 --batch 16 --steps 5 > $OUT/torch_probe.log 2>&1
+# afterwards, here: copy the summaries into profiles/ (see profiles/README.md) and run  python tools/merge_counters.py profiles/$TAG
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -size +4M -delete
 ls $OUT | head -40

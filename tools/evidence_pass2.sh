@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round evidence, pass 2 of 2 (through gpurun), AFTER the counter summaries of pass 1 were copied into profiles/: the default bench
 # line (reads them for roofline.traffic / sq_counters), the 1-rank launcher lines, and the whole -m gpu suite.
-#   bash tools/evidence_pass2.sh r05
+#   bash tools/evidence_pass2.sh r06
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/${TAG}_final; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-300 $OUT/bench.json

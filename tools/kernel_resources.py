@@ -30,7 +30,9 @@ def main():
         for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', asm, re.S):
             name, desc = m.group(1), m.group(2)
             g = lambda k: int(re.search(r'\.amdhsa_' + k + r'\s+(\S+)', desc).group(1))
-            body = re.search(r'^' + re.escape(name) + r':.*?s_endpgm', asm, re.S | re.M).group(0).split('\n')
+            # the whole function body up to its .Lfunc_end label (NOT to the first s_endpgm: a kernel with an early exit has several,
+            # and round 5's table reported 0 MFMA instructions for every k_conv_igemm<64,64,...> instantiation because of it)
+            body = re.search(r'^' + re.escape(name) + r':.*?^\.Lfunc_end\d+:', asm, re.S | re.M).group(0).split('\n')
             mf = [i for i, l in enumerate(body) if 'v_mfma' in l]
             sc = [i for i, l in enumerate(body) if re.match(r'\s*scratch_(load|store)', l)]
             inloop = sum(1 for i in sc if mf and mf[0] < i < mf[-1])
