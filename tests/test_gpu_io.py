@@ -233,8 +233,9 @@ def test_prepare_data_triplets_match_the_reference_pipeline(tmp_path):
     assert np.array_equal(np.asarray(Image.open(__import__('io').BytesIO(sr_b))), np.asarray(Image.open(os.path.join(out, 'sr_16_128', '00000.png'))))
 
 
-def test_infer_py_call_sequence(tmp_path):
-    """The call sequence of the reference's infer.py (lines 44-90) through the drop-in packages only: create_dataset /
+def test_infer_py_call_sequence(tmp_path, monkeypatch):
+    """(SR3_VAL_CHAIN_BATCH=1: one chain per image, as the reference runs them -- this test replays each chain's own RNG draws.)
+    The call sequence of the reference's infer.py (lines 44-90) through the drop-in packages only: create_dataset /
     create_dataloader('val') on PNG triplets -> Model.create_model -> set_new_noise_schedule(val) -> per image
     feed_data / test(continous=True) / get_current_visuals(need_LR=False) -> Metrics.tensor2img / save_img of HR, INF, the
     SR process grid and the final SR -- and the final image equals the oracle's reverse loop fed the same draws."""
@@ -244,6 +245,7 @@ def test_infer_py_call_sequence(tmp_path):
     from PIL import Image
     from helpers import DESCS, SCHEDS, load_golden, opt_for
     from oracle import sr3_oracle as SO
+    monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', '1')
     root = str(tmp_path / 'ds')
     _write_triplets(root, 2, l=4, r=16)
     dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)

@@ -681,13 +681,14 @@ def test_conv_weight_gradient_per_op(case, split):
     F.conv2d(a, w, None, stride=stride, padding=pad).backward(dy.double())
     ref = w.grad
     g = lambda t: None if t is None else t.to(d)
+    x0d, x1d, ssd, dyd = g(G.nhwc(x0)), (None if x1 is None else g(G.nhwc(x1))), g(ss), g(G.nhwc(dy))      # (kept alive across the calls)
 
     def run(sp):
         nb = int(lib.sr3_conv_wgrad_scratch_bytes(B, H, W, ups, stride, k, C0, C1, Cout, sp))
         scratch = torch.empty(max(nb, 16), dtype=torch.uint8, device=d)
         dw = torch.full((Cout, k * k, Cin), float('nan'), device=d)
-        L.check(lib.sr3_conv_wgrad_f32(L.ptr(g(G.nhwc(x0))), C0, L.ptr(None if x1 is None else g(G.nhwc(x1))), C1, B, H, W, ups, stride, k, Cout,
-                                       L.ptr(g(ss)), act, L.ptr(g(G.nhwc(dy))), L.ptr(dw), sp, L.ptr(scratch), nb, G.stream()))
+        L.check(lib.sr3_conv_wgrad_f32(L.ptr(x0d), C0, L.ptr(x1d), C1, B, H, W, ups, stride, k, Cout,
+                                       L.ptr(ssd), act, L.ptr(dyd), L.ptr(dw), sp, L.ptr(scratch), nb, G.stream()))
         torch.cuda.synchronize()
         got = dw.cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2).double()
         return (got - ref).norm().item() / ref.norm().item()
