@@ -276,6 +276,11 @@ def test_validation_items_batched_into_one_chain_single_process(tmp_path, monkey
     import model as Model
     root = str(tmp_path / 'ds')
     _write_triplets(root, 5, l=4, r=16)
+    # (the reference's validation loader forks one worker; forking THIS process -- hundreds of GPU tests' worth of HIP mappings --
+    #  takes tens of seconds per pass on the GPU box: load in-process here, the batches are the same)
+    import torch.utils.data as _tud
+    _DL = _tud.DataLoader
+    monkeypatch.setattr(_tud, 'DataLoader', lambda *a, **k: _DL(*a, **dict(k, num_workers=0)))
     monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', '4')
     dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
     loader = Data.create_dataloader(Data.create_dataset(dopt, 'val'), dopt, 'val')

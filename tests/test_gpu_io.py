@@ -245,6 +245,11 @@ def test_infer_py_call_sequence(tmp_path, monkeypatch):
     from PIL import Image
     from helpers import DESCS, SCHEDS, load_golden, opt_for
     from oracle import sr3_oracle as SO
+    # (the reference's validation loader forks one worker; forking THIS process -- hundreds of GPU tests' worth of HIP mappings --
+    #  takes tens of seconds per pass on the GPU box: load in-process here, the batches are the same)
+    import torch.utils.data as _tud
+    _DL = _tud.DataLoader
+    monkeypatch.setattr(_tud, 'DataLoader', lambda *a, **k: _DL(*a, **dict(k, num_workers=0)))
     monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', '1')
     root = str(tmp_path / 'ds')
     _write_triplets(root, 2, l=4, r=16)
