@@ -373,6 +373,15 @@ def roofline_from_profile(netG, x, cond, reps=3):
         counters = {'dominant_kernel': by_kernel(sq), 'attention': sq.get('attention')}
     except (OSError, ValueError):
         pass
+    rocprof_avg_us = None
+    try:        # the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command
+        import csv
+        for row in csv.DictReader(open(os.path.join(ROOT, 'profiles', PROFILE_ROUND + '_bench_kernel_stats.csv'))):
+            if row['Name'].replace('void ', '').startswith(kname + '('):
+                rocprof_avg_us = float(row['AverageNs']) / 1e3
+                break
+    except (OSError, KeyError, ValueError):
+        pass
     is_wino = dom in WINO_KINDS
     is_split = dom in WINO_SPLIT_KINDS or ((not is_wino) and names[dom].split(',')[4] == '1')
     # split kernels: six bf16 MFMA products per fp32 product -> fp32-equivalent peak = bf16 dense peak / 6
@@ -424,7 +433,10 @@ def roofline_from_profile(netG, x, cond, reps=3):
                 peak=peak, unit='TFLOP/s', frac=executed / peak, traffic=traffic, **extra,
                 traffic_note='bytes/launch = (2*FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc passes, profiles/%s_bench_hbm_pmc.csv'
                              % PROFILE_ROUND,
-                avg_launch_us=t_ms / launches * 1e3, launches_per_forward=launches // reps,
+                avg_launch_us=t_ms / launches * 1e3, rocprof_avg_launch_us=rocprof_avg_us,
+                avg_launch_note='avg_launch_us: HIP events around each launch of an eagerly launched forward (includes the launch gap of an '
+                                'empty queue, ~5 us); rocprof_avg_launch_us: kernel begin-to-end in profiles/%s_bench_kernel_stats.csv' % PROFILE_ROUND,
+                launches_per_forward=launches // reps,
                 flops_per_launch=flops / launches, share_of_forward_time=(t_ms / reps) / total_ms,
                 all_halo_kernels_tflops=all_tf, sq_counters=counters, by_op_kind=detail)
 

@@ -380,8 +380,14 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const ConvParams p, int r
         const size_t m = row0 + r;
         if (m >= M) break;
         f32x4 v = cb;
-        for (int s = 0; s < p.ksplit; ++s)
-          v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n);
+        // four slabs in flight (round 6; one load per iteration made the wave wait for each slab in turn); same order of additions
+        auto slab = [&](int s) { return *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n); };
+        int s = 0;
+        for (; s + 4 <= p.ksplit; s += 4) {
+          const f32x4 a0 = slab(s), a1 = slab(s + 1), a2 = slab(s + 2), a3 = slab(s + 3);
+          v += a0; v += a1; v += a2; v += a3;
+        }
+        for (; s < p.ksplit; ++s) v += slab(s);
         const int b = (int)(m / HoWo);
         if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
         if (p.res0) {
