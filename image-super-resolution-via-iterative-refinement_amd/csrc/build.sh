@@ -11,7 +11,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 if [ "${1:-}" = "--clean" ]; then rm -rf "$BUILD"; shift; fi
 mkdir -p "$BUILD"
-SRCS="conv_igemm conv3x3_halo conv3x3_wino conv3x3_wino2 small_kernels attention plan train_kernels train_small wgrad attention_bwd train_plan io_metrics resize"
+SRCS="conv_igemm gemm1x1 conv3x3_halo conv3x3_wino conv3x3_wino2 small_kernels attention plan train_kernels train_small wgrad attention_bwd train_plan io_metrics resize"
 pids=()
 for f in $SRCS; do
   o=$BUILD/$f.o

@@ -524,6 +524,22 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
       if ((long)cdiv(M, c.bm) * cdiv(p.Cout, c.bn) >= 448) { tile_cfg = order[k]; break; }
     }
   }
+  if (tile_cfg == 22) {
+    // 1x1 GEMM kernel (gemm1x1.hip; two workgroups per CU): split K below one round of workgroups, >= 4 k-steps (128 channels) per split
+    if (ksplit == 0) {
+      const long tiles = (long)(M / 64) * (p.Cout / 128);
+      int ks = 1;
+      if (tiles < 128 && tiles > 0) {
+        ks = (int)((512 + tiles - 1) / tiles);
+        const int cap = nchunks / 4 > 1 ? nchunks / 4 : 1;
+        if (ks > cap) ks = cap;
+        if (ks > 16) ks = 16;
+      }
+      while (ks > 1 && (long)(ks - 1) * cdiv(nchunks, ks) >= nchunks) --ks;
+      ksplit = ks;
+    }
+    return;
+  }
   if (ksplit == 0 && tile_cfg == 11) {
     // Winograd kernel: one 8-wave workgroup per CU, so one full round of 256 is the target (512 for the four-wave workgroups of
     // conv3x3_wino2.hip, two per CU); a split keeps >= 4 chunks (64 input channels)
@@ -625,7 +641,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   conv_pick(p, tile_cfg, ksplit);
   p.ksplit = ksplit;
-  if (p.ostat && ksplit == 1 && (tile_cfg < 5)) { set_error("conv: fused output statistics need the halo kernel or split-K"); return SR3_E_UNSUPPORTED; }
+  if (p.ostat && ksplit == 1 && (tile_cfg < 5 || tile_cfg >= 22)) { set_error("conv: fused output statistics need the halo kernel or split-K"); return SR3_E_UNSUPPORTED; }
   if (p.ostat && ksplit > 1 && splitk_rows_per_block(p, true) == 0) { set_error("conv: Ho*Wo does not allow fused split-K statistics"); return SR3_E_UNSUPPORTED; }
   { static const char* e = getenv("SR3_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   if (ksplit > 1) {
@@ -635,9 +651,11 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   }
   int rc;
   const bool k3 = p.ksize == 3;
-  if (p.x2_w && (tile_cfg < 5 || tile_cfg == 11 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
+  if (p.x2_w && (tile_cfg < 5 || tile_cfg == 11 || tile_cfg >= 22 || p.ups)) { set_error("conv: the fused 1x1 segment needs the halo kernel without upsampling"); return SR3_E_UNSUPPORTED; }
   if (p.x2_w && ((p.x2_C0 & 3) || (p.x2_C1 & 3) || !p.x2_src0 || (p.x2_C1 > 0 && !p.x2_src1))) { set_error("conv: bad x2 segment"); return SR3_E_BADARG; }
-  if (tile_cfg == 11) {
+  if (tile_cfg == 22) {
+    rc = gemm1x1_forward(p, 2, st);
+  } else if (tile_cfg == 11) {
     rc = conv3x3_wino_forward(p, p.wino_u, st);
   } else if (tile_cfg >= 5) {
     HaloGeom g;

@@ -408,7 +408,15 @@ struct Builder {
       o.tile_cfg = P->gemm_tile; o.ksplit = P->ksplit;       // A/B knob: one im2col tile for every conv of that kernel
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
-    if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->wsplit_of.count(w)) {
+    if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->gemm2 && P->tile_cfg == 0 && P->gemm_tile == 0 && P->wsplit_of.count(w)) {
+      // plan option gemm2: 1x1 stride-1 convs the plain GEMM kernel fits (gemm1x1.hip)
+      if (gemm1x1_fits(c, 2)) {
+        o.tile_cfg = 22; o.ksplit = P->ksplit;
+        conv_pick(c, o.tile_cfg, o.ksplit);
+        o.has_wsplit = true; o.wsplit_off = P->wsplit_of[w];
+      }
+    }
+    if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->gemm_wpre && P->wsplit_of.count(w)) {
       o.has_wsplit = true; o.wsplit_off = P->wsplit_of[w];       // the SPLIT tile reads its weights pre-split from the derived buffer
     }
     if (o.has_drop && o.tile_cfg == 9) {       // no dropout instantiation of the 8-wave tile
@@ -623,9 +631,10 @@ void layout_derived(sr3_plan* P) {
   // (3x3 stride 2; Cout <= 64 stays on the fp32 MFMA: Builder::conv)
   P->wsplits.clear();
   P->wsplit_of.clear();
-  if (P->gemm_split && P->gemm_wpre) {
+  if (P->gemm_split && (P->gemm_wpre || P->gemm2)) {
     auto regw = [&](size_t w, int Cout, int taps, int Cin) {
       if (Cin & 3) return;
+      if (!P->gemm_wpre && (taps != 1 || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take
       P->wsplits.push_back({w, Cout, taps, Cin, dcur});
       P->wsplit_of[w] = dcur;
       dcur += igemm_wsplit_floats(Cout, taps, Cin);
@@ -758,7 +767,7 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
           }
           c.wino_u = P->derived_ptr + o.wino_off;
         }
-        if (o.has_wsplit && o.tile_cfg >= 1 && o.tile_cfg <= 4 && c.igemm_split) {
+        if (o.has_wsplit && ((o.tile_cfg >= 1 && o.tile_cfg <= 4) || o.tile_cfg == 22) && c.igemm_split) {
           if (!P->derived_ptr || P->derived_from != params) {
             set_error("the plan's derived (pre-split 1x1 / stride-2) weights are not bound or stale: call sr3_plan_bind_derived + sr3_plan_prepare_derived");
             return SR3_E_BADARG;
@@ -1035,6 +1044,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "attn_split")) { const int prev = plan->attn_split; plan->attn_split = value; return prev; }   // no rebuild
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
+  else if (!strcmp(key, "gemm2")) slot = &plan->gemm2;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino2")) slot = &plan->wino2;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild
@@ -1051,7 +1061,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
-  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
+  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre || slot == &plan->gemm2) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }
@@ -1194,6 +1204,8 @@ int sr3_unet_forward_profile(sr3_plan* plan, const float* x_nchw, const float* c
         //        tile of the 8x8 maps, 555: its 3 x bf16 split instantiation (plan option wino_split)
         {
           static const int base[13] = {0, 1, 2, 3, 4, 5, 6, 105, 106, 205, 305, 405, 505};
+          if (o.tile_cfg == 22) kind += 182;                                               // 232: the 1x1 GEMM kernel (gemm1x1.hip)
+          else
           kind += base[(o.tile_cfg == 11 && o.cp.wino_split) ? 12 : o.tile_cfg] + ((o.tile_cfg >= 5 && o.has_x2) ? 2 : 0);
           if (o.tile_cfg == 11 && o.cp.wino_split == 2) kind += 20;                         // 575: the two-workgroups-per-CU split kernel (conv3x3_wino2.hip)
           if (o.tile_cfg >= 1 && o.tile_cfg <= 4 && o.cp.igemm_split) kind += 600;           // 651-654: the im2col tiles on their 3 x bf16 split instantiation
@@ -1263,10 +1275,12 @@ int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, in
   const bool wsplit = tile_cfg == 12 || tile_cfg == 13;     // tile 11 on the 3 x bf16 split instantiation (13: the 8 x 16 tile of conv3x3_wino2.hip)
   if (wsplit) { c.wino_split = tile_cfg - 11; tile_cfg = 11; }
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }     // the im2col tiles 1-4 on their 3 x bf16 split instantiation
-  if (tile_cfg >= 18 && tile_cfg <= 21) {
+  if (tile_cfg >= 18 && tile_cfg <= 22) {
     // ... with the weights pre-split into bf16 planes (what a plan does, in its derived buffer): derived here, behind the split-K
-    // slabs in `scratch` (sr3_conv_scratch_bytes accounts for them)
-    c.igemm_split = 1; tile_cfg -= 17;
+    // slabs in `scratch` (sr3_conv_scratch_bytes accounts for them).  22: the 1x1 GEMM kernel of gemm1x1.hip (64 x 128 tile)
+    c.igemm_split = 1;
+    if (tile_cfg == 22 && !gemm1x1_fits(c, 2)) { set_error("conv: the 1x1 GEMM kernel (tile 22) does not fit this problem"); return SR3_E_UNSUPPORTED; }
+    if (tile_cfg <= 21) tile_cfg -= 17;
     const size_t slab = conv_splitk_bytes(c, tile_cfg, ksplit);
     const size_t wb = igemm_wsplit_floats(Cout, ksize * ksize, c.C0 + c.C1) * sizeof(float);
     if (!scratch || scratch_bytes < slab + wb) { set_error("conv: scratch too small for the pre-split weights (%zu < %zu)", scratch_bytes, slab + wb); return SR3_E_NOMEM; }
@@ -1363,6 +1377,10 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
   }
   size_t extra = 0;
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
+  if (tile_cfg == 22) {      // the 1x1 GEMM kernel: stride 1, pre-split weights behind the slabs
+    c.igemm_split = 1; c.Hs = Ho; c.Ws = Wo; c.stride = 1;
+    return conv_splitk_bytes(c, tile_cfg, ksplit) + igemm_wsplit_floats(Cout, 1, Cin) * sizeof(float);
+  }
   if (tile_cfg >= 18 && tile_cfg <= 21) {      // + the pre-split weights behind the slabs
     c.igemm_split = 1; tile_cfg -= 17;
     extra = igemm_wsplit_floats(Cout, ksize * ksize, Cin) * sizeof(float);

@@ -119,6 +119,10 @@ struct sr3_plan {
                              // again (1.50-1.52 vs 1.44-1.46 ms over the 33 launches, profiles/r06_gemm_wpre_fragment_major.txt: every wave
                              // fetches its own fragments, 3x the weight traffic of one staged copy per workgroup, and the A staging that
                              // bounds these launches is unchanged) -- off by default, an A/B knob.  0: weights split while staged (14-17)
+  int gemm2 = 1;             // 1x1 stride-1 convs (res_conv, the attention projections) on the plain GEMM kernel of gemm1x1.hip where it fits
+                             // (Cout % 128 == 0, channels % 32 == 0, rows % 64 == 0): pre-split weights in fragment order read straight from
+                             // global memory, A rows split once per 128 output channels, staging arithmetic hand-placed between the MFMAs
+                             // (round 6; 27 of the 33 launches of the C2 forward: 1.09 -> 0.80 ms, profiles/r06_gemm1x1.txt).  0: the im2col kernel
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;

@@ -195,6 +195,9 @@ int splitk_rows_per_block(const ConvParams& p, bool stats);
 // pre-split weights of the im2col SPLIT instantiations: floats of the derived block for `numel` weights, and the transform
 size_t igemm_wsplit_floats(int Cout, int taps, int Cin);
 int igemm_split_weights(const float* w, int Cout, int taps, int Cin, float* out, hipStream_t st);
+// 1x1 stride-1 convs as a plain GEMM on the split arithmetic (gemm1x1.hip; tile_cfg 22: 64 x 128 tile, mi = 2; needs w_split)
+bool gemm1x1_fits(const ConvParams& p, int mi);
+int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st);
 // profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the
 // split-K reduce kernel (then resets the pointer).  Thread-local.
 void conv_set_mid_event(hipEvent_t ev);

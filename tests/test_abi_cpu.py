@@ -164,6 +164,22 @@ def test_plan_launch_list_no_gpu():
     wops = p.op_list(16)
     assert len(wops) == p.num_ops(16) == 168      # (round 3: the input conv writes its own GroupNorm partials: no statistics pass)
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
+    # plan option gemm2 (default 1, round 6): the 1x1 stride-1 convs with Cout % 128 == 0 run the plain GEMM kernel of gemm1x1.hip
+    # (tile 22; rows % 64 == 0 and channels % 32 == 0 hold for every layer of this network), reading their weights pre-split in MFMA
+    # fragment order from the derived buffer (6 bytes per weight); the Cout = 64 res_convs and the Downsample convs keep the im2col kernel
+    dconvs = [o for o in wops if o['kind'] == 50]
+    for o in dconvs:
+        assert (o['tile_cfg'] == 22) == (o['ksize'] == 1 and o['stride'] == 1 and o['cout'] % 128 == 0), o
+        if o['tile_cfg'] == 22:        # split-K only below 128 workgroups (the 8x8 maps with Cout = 512)
+            assert (o['ksplit'] > 1) == ((16 * o['h_out'] * o['w_out'] // 64) * (o['cout'] // 128) < 128), o
+    assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 27
+    nbytes_gemm2 = int(p.lib.sr3_plan_derived_bytes(p.handle))
+    p.set_option('gemm2', 0)           # the rest of this test walks the im2col options with gemm2 off
+    assert nbytes_gemm2 - int(p.lib.sr3_plan_derived_bytes(p.handle)) == 6 * sum(o['cout'] * o['cin'] for o in dconvs if o['tile_cfg'] == 22)
+    wops0 = p.op_list(16)
+    for a, b in zip(wops, wops0):
+        assert a['kind'] == b['kind'] and a['flops'] == b['flops'] and (a['tile_cfg'] == b['tile_cfg'] or (a['tile_cfg'] == 22 and b['tile_cfg'] == 16))
+    wops = wops0
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:
         assert (o['tile_cfg'] in (11, 12, 13)) == (o['ksize'] == 3 and o['stride'] == 1), o

@@ -353,7 +353,7 @@ GEMM_SPLIT_CASES = [
 ]
 
 
-@pytest.mark.parametrize('tile,ksplit', [(14, 1), (16, 1), (15, 2), (18, 1), (19, 1), (20, 1), (21, 1), (19, 2), (20, 3), (0, 0)])
+@pytest.mark.parametrize('tile,ksplit', [(14, 1), (16, 1), (15, 2), (18, 1), (19, 1), (20, 1), (21, 1), (19, 2), (20, 3), (22, 1), (22, 2), (22, 0), (0, 0)])
 @pytest.mark.parametrize('case', GEMM_SPLIT_CASES, ids=[c[0] for c in GEMM_SPLIT_CASES])
 def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
     """Gate of the `gemm_split` plan option (tiles 14-17: the im2col kernel's 3 x bf16 split instantiations -- operands split
@@ -364,6 +364,11 @@ def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
     if tile in (14, 17, 18, 21) and case[6] <= 64:
         pytest.skip('128-wide tiles are not used for Cout <= 64')
     src0, src1, w, kw = _make_case(case, seed=11)
+    if tile == 22 and (case[7] != 1 or case[8] != 1 or case[6] % 128):
+        # tile 22 = the plain GEMM kernel of gemm1x1.hip (plan option gemm2): 1x1 stride 1, Cout % 128 == 0 only -- asserted, not skipped
+        with pytest.raises(L.Sr3Error, match='does not fit'):
+            G.conv_call(src0, src1, w, tile_cfg=22, ksplit=ksplit, **kw)
+        return
     ref = G.conv_ref(src0, src1, w, **kw)
     got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
     base, _ = G.conv_call(src0, src1, w, tile_cfg=3, ksplit=ksplit, **kw)
@@ -379,7 +384,7 @@ def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
         return
     assert rms_s <= 1.1 * rms_f + 1e-9 * scale, (rms_s, rms_f)
     assert e_s <= 1.5 * e_f + 1e-8 * scale, (e_s, e_f)
-    if tile >= 18:      # pre-split weights are the same three bf16 terms the kernel would have built itself: identical results
+    if 18 <= tile <= 21:      # pre-split weights are the same three bf16 terms the kernel would have built itself: identical results
         same, _ = G.conv_call(src0, src1, w, tile_cfg=tile - 4, ksplit=ksplit, **kw)
         assert torch.equal(got, same), 'pre-split weights changed the result'
 
@@ -392,7 +397,7 @@ GEMM_STRESS_CASES = [
 ]
 
 
-@pytest.mark.parametrize('tile', [3, 16, 18, 19, 20, 21], ids=['fp32', 'split_64x64', 'pre_128x128', 'pre_128x64', 'pre_64x64', 'pre_64x128'])
+@pytest.mark.parametrize('tile', [3, 16, 18, 19, 20, 21, 22], ids=['fp32', 'split_64x64', 'pre_128x128', 'pre_128x64', 'pre_64x64', 'pre_64x128', 'gemm1x1'])
 @pytest.mark.parametrize('ksplit', [1, 2])
 @pytest.mark.parametrize('case', GEMM_STRESS_CASES, ids=[c[0] for c in GEMM_STRESS_CASES])
 def test_gemm_split_stress_absolute_bound(case, ksplit, tile):
@@ -422,6 +427,10 @@ def test_gemm_split_stress_absolute_bound(case, ksplit, tile):
         if act == 2:
             a = a * torch.sigmoid(a)
     src0, src1 = (x[:, :C0].contiguous(), x[:, C0:].contiguous()) if C1 else (x, None)
+    if tile == 22 and (k != 1 or stride != 1 or Cout % 128):
+        with pytest.raises(L.Sr3Error, match='does not fit'):        # the plain GEMM kernel: 1x1 stride 1 only
+            G.conv_call(src0, src1, w, tile_cfg=22, ksplit=ksplit, **kw)
+        return
     got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
     ref = G.conv_ref(src0, src1, w, **kw)
     mag = F.conv2d(a.abs(), w.double().abs(), None, stride=stride, padding=k // 2) + bias.double().abs()[None, :, None, None]

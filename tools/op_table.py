@@ -14,7 +14,7 @@ TILE = {1: 'im2col 128x128', 2: 'im2col 128x64', 3: 'im2col 64x64', 4: 'im2col 6
         9: 'halo 256x128', 11: 'winograd', 12: 'winograd 3xbf16', 13: 'winograd 3xbf16 4w',
         14: 'im2col 3xbf16 128x128', 15: 'im2col 3xbf16 128x64', 16: 'im2col 3xbf16 64x64', 17: 'im2col 3xbf16 64x128',
         18: 'im2col 3xbf16 128x128 presplit-w', 19: 'im2col 3xbf16 128x64 presplit-w', 20: 'im2col 3xbf16 64x64 presplit-w',
-        21: 'im2col 3xbf16 64x128 presplit-w'}
+        21: 'im2col 3xbf16 64x128 presplit-w', 22: 'gemm1x1 3xbf16 64x128', 23: 'gemm1x1 3xbf16 128x128'}
 
 
 def main():
