@@ -688,6 +688,7 @@ int conv_forward(const ConvParams& pin, int tile_cfg, int ksplit, float* scratch
   if (rc) return rc;
   if (ksplit > 1) {
     if (g_mid_event) { SR3_HIP(hipEventRecord(g_mid_event, st)); g_mid_event = nullptr; }
+    if (p.fold) return splitk_reduce_fold(p, *p.fold, st);      // the reduce per (image, consumer group) + the next op's GroupNorm fold
     const int rpb = splitk_rows_per_block(p, p.ostat != nullptr);
     const long M = (long)p.B * p.Ho * p.Wo;
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, p, rpb);

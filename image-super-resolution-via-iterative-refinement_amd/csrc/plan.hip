@@ -326,10 +326,52 @@ struct Builder {
     Op o; o.kind = OP_STATS;
     o.a = t.off; o.b = t.stat_off; o.i0 = t.H * t.W; o.i1 = t.C;
     ops.push_back(o);
+    last_stats_op = (int)ops.size() - 1; last_stats_h = h;
+  }
+  int last_conv_op = -1, last_conv_out = -1, last_stats_op = -1, last_stats_h = -1;
+  // plan option fold_fuse: can the kernel that completes `fresh` (one of x0 / x1) also do this fold?  Fills the op's FoldTail fields.
+  bool fuse_fold_into(Op& L, int fresh, int x0, int x1, size_t gamma, size_t beta, size_t ss_rel, size_t mr_rel, bool has_mr) {
+    const int other = fresh == x0 ? x1 : x0;
+    const int Cf = T[x0].C + (x1 >= 0 ? T[x1].C : 0);
+    const int c_off = fresh == x0 ? 0 : T[x0].C;
+    if (!fold_tail_fits(T[fresh].C, Cf, c_off, P->d.norm_groups)) return false;
+    if (other >= 0 && !T[other].stats_done) return false;
+    L.fold_fused = true;
+    L.f_Ctot = Cf; L.f_coff = c_off;
+    L.f_has_o = other >= 0;
+    if (other >= 0) { L.f_ostat = T[other].stat_off; L.f_oC = T[other].C; L.f_oT = T[other].stat_T; L.f_ooff = fresh == x0 ? T[x0].C : 0; }
+    L.f_gamma = gamma; L.f_beta = beta; L.f_ss_rel = ss_rel; L.f_mr_rel = mr_rel; L.f_has_mr = has_mr;
+    T[fresh].stat_T = 1;              // the fused kernel holds whole-image sums: one partial per image
+    return true;
   }
   void fold(int x0, int x1, size_t gamma, size_t beta) {
+    const int Cfu = T[x0].C + (x1 >= 0 ? T[x1].C : 0);
+    size_t ss_rel = 0, mr_rel = 0;
+    auto take_slots = [&]() {
+      if (train) {
+        ss_rel = gn_cursor; gn_cursor += ((size_t)B * Cfu * 2 * sizeof(float) + 255) & ~(size_t)255;
+        mr_rel = mr_cursor; mr_cursor += ((size_t)B * P->d.norm_groups * 2 * sizeof(float) + 255) & ~(size_t)255;
+      }
+      cur_ss = ss_rel; cur_mr = mr_rel; cur_gamma = gamma; cur_beta = beta;
+      max_cin = std::max(max_cin, Cfu);
+    };
+    if (P->fold_fuse && !ops.empty()) {
+      // (a) the op just emitted is a split-K conv whose reduce writes the statistics of x0 / x1: its reduce folds too
+      Op& L = ops.back();
+      if (last_conv_op == (int)ops.size() - 1 && L.kind == OP_CONV && L.ksplit > 1 && L.has_ostat && (last_conv_out == x0 || last_conv_out == x1)) {
+        take_slots();
+        if (fuse_fold_into(L, last_conv_out, x0, x1, gamma, beta, ss_rel, mr_rel, train)) return;
+        if (train) { gn_cursor = ss_rel; mr_cursor = mr_rel; }       // (not fused: the slots are taken again below)
+      }
+    }
     ensure_stats(x0);
     if (x1 >= 0) ensure_stats(x1);
+    if (P->fold_fuse && !ops.empty() && last_stats_op == (int)ops.size() - 1 && (last_stats_h == x0 || last_stats_h == x1)) {
+      // (b) ... or a stand-alone statistics pass of x0 / x1: it folds too
+      take_slots();
+      if (fuse_fold_into(ops.back(), last_stats_h, x0, x1, gamma, beta, ss_rel, mr_rel, train)) return;
+      if (train) { gn_cursor = ss_rel; mr_cursor = mr_rel; }
+    }
     Op o; o.kind = OP_FOLD;
     o.a = T[x0].stat_off; o.i0 = T[x0].C; o.i3 = T[x0].stat_T;
     o.has_st1 = x1 >= 0;
@@ -480,6 +522,7 @@ struct Builder {
       }
     }
     ops.push_back(o);
+    last_conv_op = (int)ops.size() - 1; last_conv_out = out;
     flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(C0 + C1) * ksize * ksize;
     return out;
   }
@@ -688,6 +731,17 @@ Regions infer_regions(const sr3_plan* P) {
   return r;
 }
 
+static FoldTail make_fold_tail(const Op& o, int groups, const float* params, char* ws, const Regions& R) {
+  FoldTail f;
+  memset(&f, 0, sizeof(f));
+  f.groups = groups; f.Ctot = o.f_Ctot; f.c_off = o.f_coff;
+  if (o.f_has_o) { f.ostat = reinterpret_cast<const double*>(ws + R.stats_off + o.f_ostat); f.oC = o.f_oC; f.oT = o.f_oT; f.o_off = o.f_ooff; }
+  f.gamma = params + o.f_gamma; f.beta = params + o.f_beta; f.eps = 1e-5f;
+  f.ss = reinterpret_cast<float*>(ws + R.ss_off + o.f_ss_rel);
+  f.mr = o.f_has_mr ? reinterpret_cast<float*>(ws + R.mr_off + o.f_mr_rel) : nullptr;
+  return f;
+}
+
 int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond, int cond_channels, const float* level,
                 const int64_t* tstep, const float* freq, const float* level_table, const int* step_dev,
                 const float* params, char* ws, float* eps_out, int B, hipStream_t st,
@@ -726,6 +780,11 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         break;
       }
       case OP_STATS:
+        if (o.fold_fused) {
+          FoldTail ft = make_fold_tail(o, d.norm_groups, params, ws, R);
+          rc = chan_stats_fold(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1, reinterpret_cast<double*>(ws + R.stats_off + o.b), ft, st);
+          break;
+        }
         rc = chan_stats(reinterpret_cast<const float*>(ws + o.a), B, o.i0, o.i1,
                         reinterpret_cast<double*>(ws + R.stats_off + o.b), st);
         break;
@@ -775,6 +834,8 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
           c.w_split = P->derived_ptr + o.wsplit_off;
         }
         if (mid && o.ksplit > 1) conv_set_mid_event(mid[op_index - 1]);
+        FoldTail ft;
+        if (o.fold_fused) { ft = make_fold_tail(o, d.norm_groups, params, ws, R); c.fold = &ft; }
         rc = conv_forward(c, o.tile_cfg, o.ksplit, reinterpret_cast<float*>(ws + R.scratch_off), R.scratch_bytes, st);
         break;
       }
@@ -1045,6 +1106,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm2")) slot = &plan->gemm2;
+  else if (!strcmp(key, "fold_fuse")) slot = &plan->fold_fuse;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino2")) slot = &plan->wino2;
   else if (!strcmp(key, "loss_l2")) { const int prev = plan->loss_l2; plan->loss_l2 = value; return prev; }   // no rebuild

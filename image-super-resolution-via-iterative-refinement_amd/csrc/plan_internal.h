@@ -54,6 +54,11 @@ struct Op {
   size_t ss_rel = 0, mr_rel = 0;   // GroupNorm tables: offset inside the scale/shift region (0 in inference)
   bool has_mr = false, has_drop = false;
   unsigned drop_key = 0;
+  // the NEXT op's GroupNorm fold done by this op's last kernel (plan option fold_fuse; FoldTail in sr3_common.h): a split-K conv's
+  // reduce, or the stand-alone statistics pass
+  bool fold_fused = false, f_has_o = false, f_has_mr = false;
+  int f_Ctot = 0, f_coff = 0, f_oC = 0, f_oT = 0, f_ooff = 0;
+  size_t f_ostat = 0, f_gamma = 0, f_beta = 0, f_ss_rel = 0, f_mr_rel = 0;
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
   size_t wino_off = 0;             // tile_cfg 11: float offset of this conv's transformed filters in the derived buffer
@@ -119,6 +124,8 @@ struct sr3_plan {
                              // again (1.50-1.52 vs 1.44-1.46 ms over the 33 launches, profiles/r06_gemm_wpre_fragment_major.txt: every wave
                              // fetches its own fragments, 3x the weight traffic of one staged copy per workgroup, and the A staging that
                              // bounds these launches is unchanged) -- off by default, an A/B knob.  0: weights split while staged (14-17)
+  int fold_fuse = 1;         // the GroupNorm fold of a consumer done by the kernel that completes its (last) source where that is a split-K
+                             // reduce or a stand-alone statistics pass (k_rows_fold; round 6): 32 of the 61 fold launches of the C2 forward
   int gemm2 = 1;             // 1x1 stride-1 convs (res_conv, the attention projections) on the plain GEMM kernel of gemm1x1.hip where it fits
                              // (Cout % 128 == 0, channels % 32 == 0, rows % 64 == 0): pre-split weights in fragment order read straight from
                              // global memory, A rows split once per 128 output channels, staging arithmetic hand-placed between the MFMAs

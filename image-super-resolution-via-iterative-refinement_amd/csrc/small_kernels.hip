@@ -157,6 +157,146 @@ int gn_finalize(const double* stat0, int C0, int T0, const double* stat1, int C1
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows + fold (FoldTail, sr3_common.h; round 6): one workgroup per (image, group of the CONSUMER's GroupNorm).  It walks all pixels of
+// the image over the group's channels that live in THIS tensor -- REDUCE: summing the split-K slabs of the conv that produced it, with
+// that conv's epilogue (bias, FiLM, residual), i.e. it replaces k_splitk_reduce; otherwise reading the finished tensor, i.e. it replaces
+// k_chan_stats -- keeps {sum, sumsq} in double per channel (lanes along channel quads, a fixed-order LDS fold over the row lanes), writes
+// them as the tensor's partials (T = 1), adds the group's channels of the OTHER concat source from its partials, and writes the
+// consumer's (scale, shift) pairs: what k_gn_finalize would have done in a launch of its own.
+// ---------------------------------------------------------------------------------------------
+template <bool REDUCE>
+__global__ __launch_bounds__(256) void k_rows_fold(const ConvParams p, const FoldTail f, const float* __restrict__ x, int C, int HW,
+                                                    double* __restrict__ stat) {
+  __shared__ double red[256 * 8];
+  __shared__ double chs[2 * 128];       // per-channel {sum, sumsq} of the group, concat order
+  __shared__ float mrs[2];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / f.groups, g = blockIdx.x - b * f.groups;
+  const int cpg = f.Ctot / f.groups;
+  const int glo = g * cpg, ghi = glo + cpg;
+  const int a_lo = max(glo, f.c_off) - f.c_off, a_hi = min(ghi, f.c_off + C) - f.c_off;      // this tensor's channels of the group
+  const int na = a_hi > a_lo ? a_hi - a_lo : 0;
+  const int nq = na >> 2;
+  int nqp = 1;
+  while (nqp < nq) nqp <<= 1;
+  const int R = 256 / nqp, tq = tid % nqp, tr = tid / nqp;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (tq < nq) {
+    const int n = a_lo + 4 * tq;
+    const size_t M = (size_t)p.B * HW;
+    f32x4 cb = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (REDUCE) {
+      if (p.bias) cb += *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (p.x2_w && p.x2_bias) cb += *reinterpret_cast<const f32x4*>(p.x2_bias + n);
+    }
+    for (int r = tr; r < HW; r += R) {
+      const size_t m = (size_t)b * HW + r;
+      f32x4 v;
+      if constexpr (REDUCE) {
+        // the order of k_splitk_reduce: bias first, the slabs in split order, then FiLM and the residual -- bit-identical outputs
+        v = cb;
+        auto slab = [&](int s) { return *reinterpret_cast<const f32x4*>(p.partial + ((size_t)s * M + m) * p.Cout + n); };
+        int s = 0;
+        for (; s + 4 <= p.ksplit; s += 4) {
+          const f32x4 q0 = slab(s), q1 = slab(s + 1), q2 = slab(s + 2), q3 = slab(s + 3);
+          v += q0; v += q1; v += q2; v += q3;
+        }
+        for (; s < p.ksplit; ++s) v += slab(s);
+        if (p.film) v += *reinterpret_cast<const f32x4*>(p.film + (size_t)b * p.film_stride + n);
+        if (p.res0) {
+          if (n < p.RC0) v += *reinterpret_cast<const f32x4*>(p.res0 + m * p.RC0 + n);
+          else v += *reinterpret_cast<const f32x4*>(p.res1 + m * p.RC1 + (n - p.RC0));
+        }
+        *reinterpret_cast<f32x4*>(p.out + m * p.Cout + n) = v;
+      } else {
+        v = *reinterpret_cast<const f32x4*>(x + m * C + n);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const double dv = (double)v[e]; s1[e] += dv; s2[e] += dv * dv; }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[tid * 8 + e] = s1[e]; red[tid * 8 + 4 + e] = s2[e]; }
+  __syncthreads();
+  // this tensor's channels: fixed-order sum over the row lanes, one thread per channel
+  if (tid < na) {
+    const int q = tid >> 2, e = tid & 3;
+    double a1 = 0.0, a2 = 0.0;
+    for (int k = 0; k < R; ++k) { a1 += red[(k * nqp + q) * 8 + e]; a2 += red[(k * nqp + q) * 8 + 4 + e]; }
+    double* o = stat + ((size_t)b * C + a_lo + tid) * 2;
+    o[0] = a1; o[1] = a2;
+    const int cc = f.c_off + a_lo + tid - glo;            // position inside the group (concat order)
+    chs[2 * cc] = a1; chs[2 * cc + 1] = a2;
+  }
+  // the other source's channels of the group: its partials in slice order, one thread per channel
+  if (f.ostat) {
+    const int o_lo = max(glo, f.o_off) - f.o_off, o_hi = min(ghi, f.o_off + f.oC) - f.o_off;
+    const int no = o_hi > o_lo ? o_hi - o_lo : 0;
+    const int t2 = tid - 128;             // (the upper half of the block: runs beside the loop above)
+    if (t2 >= 0 && t2 < no) {
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      double a1 = 0.0, a2 = 0.0;
+      const double* q = f.ostat + ((size_t)b * f.oT * f.oC + o_lo + t2) * 2;
+      int t = 0;
+      for (; t + 4 <= f.oT; t += 4) {
+        const d2 q0 = *reinterpret_cast<const d2*>(q + (size_t)t * f.oC * 2), q1 = *reinterpret_cast<const d2*>(q + (size_t)(t + 1) * f.oC * 2),
+                 q2 = *reinterpret_cast<const d2*>(q + (size_t)(t + 2) * f.oC * 2), q3 = *reinterpret_cast<const d2*>(q + (size_t)(t + 3) * f.oC * 2);
+        a1 += q0[0]; a2 += q0[1]; a1 += q1[0]; a2 += q1[1]; a1 += q2[0]; a2 += q2[1]; a1 += q3[0]; a2 += q3[1];
+      }
+      for (; t < f.oT; ++t) { const d2 q0 = *reinterpret_cast<const d2*>(q + (size_t)t * f.oC * 2); a1 += q0[0]; a2 += q0[1]; }
+      const int cc = f.o_off + o_lo + t2 - glo;
+      chs[2 * cc] = a1; chs[2 * cc + 1] = a2;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0, sq = 0.0;
+    for (int k = 0; k < cpg; ++k) { s += chs[2 * k]; sq += chs[2 * k + 1]; }
+    const double cnt = (double)HW * cpg;
+    const double mean = s / cnt;
+    double var = sq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
+    mrs[0] = (float)mean; mrs[1] = rstd;
+    if (f.mr) { f.mr[((size_t)b * f.groups + g) * 2] = (float)mean; f.mr[((size_t)b * f.groups + g) * 2 + 1] = rstd; }
+  }
+  __syncthreads();
+  if (tid < cpg) {
+    const int c = glo + tid;
+    const float sc = mrs[1] * f.gamma[c];
+    float* o = f.ss + ((size_t)b * f.Ctot + c) * 2;
+    o[0] = sc;
+    o[1] = f.beta[c] - mrs[0] * sc;
+  }
+}
+
+// the group grid covers this tensor in whole channel quads, a group has at most 128 channels (LDS table) and at most 64 of them per
+// source side (lanes: 16 quads here, 128 threads for the other source)
+bool fold_tail_fits(int C, int Ctot, int c_off, int groups) {
+  if (groups <= 0 || Ctot % groups) return false;
+  const int cpg = Ctot / groups;
+  return (cpg & 3) == 0 && cpg <= 64 && (c_off & 3) == 0 && (C & 3) == 0;
+}
+
+int chan_stats_fold(const float* x, int B, int HW, int C, double* stat, const FoldTail& f, hipStream_t st) {
+  if (!fold_tail_fits(C, f.Ctot, f.c_off, f.groups)) { set_error("chan_stats_fold: grouping does not fit"); return SR3_E_UNSUPPORTED; }
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.B = B;
+  hipLaunchKernelGGL(k_rows_fold<false>, dim3(B * f.groups), dim3(256), 0, st, p, f, x, C, HW, stat);
+  SR3_LAUNCH_CHECK("k_rows_fold");
+  return SR3_OK;
+}
+
+int splitk_reduce_fold(const ConvParams& p, const FoldTail& f, hipStream_t st) {
+  if (!fold_tail_fits(p.Cout, f.Ctot, f.c_off, f.groups) || !p.ostat) { set_error("splitk_reduce_fold: grouping does not fit"); return SR3_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(k_rows_fold<true>, dim3(p.B * f.groups), dim3(256), 0, st, p, f, static_cast<const float*>(nullptr), p.Cout,
+                     p.Ho * p.Wo, p.ostat);
+  SR3_LAUNCH_CHECK("k_rows_fold");
+  return SR3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Self-test of split3_pair (sr3_common.h): every split kernel rests on x == h + m + l holding EXACTLY, and the shipped form of
 // the helper depends on two things no compiler promises -- the bf16 selector pairs staying in registers (folded into the inline
 // constant -1.0 they read as (0, -1) for both elements) and v_dot2c_f32_bf16 producing the exactly representable residual.  One

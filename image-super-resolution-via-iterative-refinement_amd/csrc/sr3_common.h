@@ -121,6 +121,27 @@ inline void dropout_consts(float p, unsigned* thresh, float* scale) {
   *scale = p > 0.f ? (float)(1.0 / (1.0 - pd)) : 1.0f;
 }
 
+// The GroupNorm fold of the op that FOLLOWS, done in the tail of the kernel that completes this tensor (round 6; plan option fold_fuse):
+// k_rows_fold (small_kernels.hip) walks the tensor per (image, consumer group) -- as the split-K reduce of a conv (ConvParams::fold)
+// or as the stand-alone statistics pass -- so a workgroup holds the whole-image sums of its group's channels: it writes them as this
+// tensor's partials (one per image: T = 1), adds the other concat source's channels of the group from ITS partials, and writes the
+// consumer's (scale, shift) pairs.  No atomics, fixed summation order; one launch instead of two (reduce / statistics + fold).
+struct FoldTail {
+  int groups, Ctot, c_off;     // the consumer's GroupNorm: `groups` over Ctot channels; this tensor is channels [c_off, c_off + C) of them
+  const double* ostat;         // the other concat source's partials [B][oT][oC][2], its channels at [o_off, o_off + oC); null: single source
+  int oC, oT, o_off;
+  const float* gamma;          // [Ctot]
+  const float* beta;
+  float eps;
+  float* ss;                   // out: [B][Ctot][2]
+  float* mr;                   // out: [B][groups][2] (mean, rstd) or null (training keeps them for the backward)
+};
+bool fold_tail_fits(int C, int Ctot, int c_off, int groups);
+// stand-alone form: statistics of x [B][HW][C] (partials [B][1][C][2] into `stat`) + the fold
+int chan_stats_fold(const float* x, int B, int HW, int C, double* stat, const FoldTail& f, hipStream_t st);
+struct ConvParams;
+int splitk_reduce_fold(const ConvParams& p, const FoldTail& f, hipStream_t st);
+
 // ---- convolution (implicit GEMM on v_mfma_f32_32x32x2_f32) --------------------------------
 // Activations are NHWC fp32.  The input is the *virtual* channel concat of up to two sources,
 // optionally nearest-upsampled x2 (gather in the address math), optionally strided.
@@ -171,6 +192,8 @@ struct ConvParams {
                        // 2: the same filters on the two-workgroups-per-CU kernel of conv3x3_wino2.hip (tile_cfg 13; 8 x 16 pixel tile)
   int igemm_split;     // im2col kernel (tile_cfg 1-4; 1x1 and stride-2 convs): 1 = its 3 x bf16 split instantiation (tile_cfg 14-17 at the ABI)
   int wgrad_split;     // weight gradient (wgrad.hip): 1 = the one-tap-per-workgroup kernel's 3 x bf16 split instantiation for the layers with > 64 channels on both sides
+  const FoldTail* fold; // host side only (conv_forward): split-K convs -- the reduce runs as k_rows_fold and does the next op's GroupNorm fold too;
+                        // ostat then holds ONE partial per image
   const void* w_split; // igemm_split: the weights pre-split into bf16 planes by igemm_split_weights (tile_cfg 18-21 at the ABI; a plan
                        // keeps them in its derived buffer); null: the kernel splits the weights while it stages them
 };

@@ -161,7 +161,12 @@ def test_plan_launch_list_no_gpu():
     # default inference plan: EVERY 3x3 stride-1 conv on the Winograd F(2x2,3x3) kernel (tile 11; round 4: the 8x8 maps too,
     # four images per workgroup tile, split-K); the res_convs of those blocks run as their own 1x1 GEMMs (the Winograd
     # kernel has no second K-segment)
-    wops = p.op_list(16)
+    # plan option fold_fuse (default 1, round 6): 31 of the 61 GroupNorm folds are done by the kernel that completes their (last) source --
+    # the split-K reduce of the conv in front of them, or the stand-alone statistics pass -- and leave the launch list
+    fops = p.op_list(16)
+    assert len(fops) == p.num_ops(16) == 137 and sum(1 for o in fops if o['kind'] == 40) == 30
+    assert [o for o in fops if o['kind'] != 40] == [o for o in (p.set_option('fold_fuse', 0), p.op_list(16))[1] if o['kind'] != 40]
+    wops = p.op_list(16)                               # (the rest of this test walks the other options with fold_fuse off)
     assert len(wops) == p.num_ops(16) == 168      # (round 3: the input conv writes its own GroupNorm partials: no statistics pass)
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     # plan option gemm2 (default 1, round 6): the 1x1 stride-1 convs with Cout % 128 == 0 run the plain GEMM kernel of gemm1x1.hip
