@@ -966,7 +966,7 @@ int build_train(sr3_plan* P, int B, int cond_channels) {
   P->t_geps_off = off; off += al((size_t)B * S * S * 4 * sizeof(float));
   P->t_inpad_off = off; off += al((size_t)B * S * S * 8 * sizeof(float));
   P->t_dwtmp_off = off; off += al(4096 * sizeof(double)) + al(max_dwtmp);      // [loss partials | dw temp]
-  P->t_embscr_off = off; off += al((size_t)B * 13 * inner * sizeof(float));
+  P->t_embscr_off = off; off += al((size_t)B * (13 + 16) * inner * sizeof(float));     // (+ the 16 row chunks of k_film_bwd_input)
   // gradient-ready marks: t_unproc_max[k] = largest arena offset (exclusive end) among the parameters whose
   // gradients are still unwritten once records k .. end have been processed (records < k + the FiLM /
   // embedding block at the arena head, which is written last)

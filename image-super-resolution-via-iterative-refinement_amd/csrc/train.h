@@ -9,7 +9,8 @@ namespace sr3 {
 // dgamma/dbeta[C], and dx0/dx1 (+=) receive the input gradient.  mr[B][G][2] = (mean, rstd).
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
-            float* dx1, hipStream_t st, unsigned drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f);
+            float* dx1, hipStream_t st, unsigned drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f,
+            float* aout = nullptr);      // aout: also write a = dropout(act(x*scale+shift)) (what apply_act would, in the same pass; round 6)
 // a = dropout(act(x*scale+shift)) over the virtual concat, materialised for the weight-gradient GEMM
 int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, int act, unsigned drop_seed,
               unsigned drop_thresh, float drop_scale, float* out, hipStream_t st);
@@ -52,7 +53,7 @@ struct EmbedBwdParams {
   const float* w1; const float* b1; const float* w2; const float* b2; const float* wf;
   const float* dfilm;     // [B][F]
   float* dw1; float* db1; float* dw2; float* db2; float* dwf; float* dbf;
-  float* scratch;         // >= B * (8 * inner) floats
+  float* scratch;         // >= B * 29 * inner floats (8 per image of the recompute, 5 of the MLP backward, 16 row-chunk partials)
 };
 int embed_backward(const EmbedBwdParams& p, hipStream_t st);
 

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
                                                          int LQ, int pix_per_block, const float* __restrict__ ss,
                                                          const float* __restrict__ mr, int groups, int act,
                                                          unsigned drop_seed, unsigned drop_thresh, float drop_scale,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, float* __restrict__ aout) {
   __shared__ double red[256 * 8];
   const int tid = threadIdx.x;
   const int C = C0 + C1;
@@ -68,21 +68,29 @@ __global__ __launch_bounds__(256) void k_act_bwd_reduce(float* __restrict__ dA, 
       const size_t pix = (size_t)b * HW + p;
       f32x4 g4 = *reinterpret_cast<const f32x4*>(dA + pix * C + c);
       const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cs);
+      f32x4 a4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float du = g4[e];
-        if (drop_thresh != 0) du *= drop_mask(drop_seed, (unsigned)(pix * C + c + e), drop_thresh, drop_scale);
+        float dm = 1.0f;
+        if (drop_thresh != 0) { dm = drop_mask(drop_seed, (unsigned)(pix * C + c + e), drop_thresh, drop_scale); du *= dm; }
+        const float u = fmaf(xv[e], sc[e], sh[e]);
+        float av = u;
         if (act == 2) {
-          const float u = fmaf(xv[e], sc[e], sh[e]);
           const float sg = sigmoid_t(u);
           du *= sg * (1.0f + u * (1.0f - sg));
+          av = u * sg;
         }
+        if (drop_thresh != 0) av *= dm;
+        a4[e] = av;
         g4[e] = du;
         const double xh = ((double)xv[e] - (double)mu[e]) * (double)rs[e];
         s[e] += (double)du;
         s2[e] += (double)du * xh;
       }
       *reinterpret_cast<f32x4*>(dA + pix * C + c) = g4;
+      // the activated (and dropped) conv input, for the weight gradient that follows: the values k_apply_act writes, without its pass over x
+      if (aout) *reinterpret_cast<f32x4*>(aout + pix * C + c) = a4;
     }
   }
 #pragma unroll
@@ -384,13 +392,13 @@ static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)
 
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
-            float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale) {
+            float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale, float* aout) {
   const int C = C0 + C1;
   if ((C0 & 3) || (C1 & 3)) { set_error("act_bwd: channels %% 4"); return SR3_E_UNSUPPORTED; }
   int LQ, cblocks, ppb, T;
   stats_geometry(B, HW, C, &LQ, &cblocks, &ppb, &T);
   hipLaunchKernelGGL(k_act_bwd_reduce, dim3(T, cblocks, B), dim3(256), 0, st, dA, x0, x1, C0, C1, HW, LQ, ppb, ss, mr,
-                     groups, act, drop_seed, drop_thresh, drop_scale, part);
+                     groups, act, drop_seed, drop_thresh, drop_scale, part, aout);
   SR3_LAUNCH_CHECK("k_act_bwd_reduce");
   hipLaunchKernelGGL(k_gn_bwd_group, dim3(B * groups), dim3(64), 0, st, part, C, T, groups, gamma, gs);
   SR3_LAUNCH_CHECK("k_gn_bwd_group");

@@ -57,6 +57,19 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   // 1x1 / 8x8 data gradients on the im2col kernel: its 3 x bf16 split instantiation, with the forward Builder's exclusion (9-tap
   // layers producing <= 64 channels stay on the fp32 MFMA: plan.hip, Builder::conv) -- build_train sizes the scratch with the same rule
   c.igemm_split = (X.P->gemm_split && !(ksize == 3 && c.Cout <= 64)) ? 1 : 0;
+  // 1x1: the plain GEMM kernel where it fits (plan option gemm2; gemm1x1.hip), its pre-split weights derived from the transposed filters
+  // into the region the Winograd data gradients use for theirs
+  if (c.igemm_split && X.P->gemm2 && gemm1x1_fits(c, 2) && igemm_wsplit_floats(Cin, 1, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
+    float* ws_ = X.at<float>(X.P->t_wu_off);
+    rc = igemm_split_weights(wt, Cin, 1, Cg, ws_, X.st);
+    if (rc) return rc;
+    c.w_split = ws_;
+    int t = 22, ks = 0;
+    conv_pick(c, t, ks);
+    if ((size_t)ks * X.B * H * W * Cin * sizeof(float) <= X.P->t_scratch_bytes || ks == 1)
+      return conv_forward(c, 22, ks, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
+    c.w_split = nullptr;
+  }
   return conv_forward(c, 0, 0, X.at<float>(X.P->t_scratch_off), X.P->t_scratch_bytes, X.st);
 }
 
@@ -128,13 +141,11 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (rc) return rc;
       rc = act_bwd(dA, X.act(r.x0), nullptr, C, 0, B, S * S, X.at<float>(P->t_gn_off + r.ss_off),
                    X.at<float>(P->t_misc_off + r.mr_off), G, 2, params + r.gamma, part, gs, grads + r.gamma,
-                   grads + r.beta, X.grad(r.x0), nullptr, st);
+                   grads + r.beta, X.grad(r.x0), nullptr, st, 0u, 0u, 1.f, X.at<float>(P->t_a_off));
       if (rc) return rc;
       ConvParams c;
       memset(&c, 0, sizeof(c));
-      float* abuf = X.at<float>(P->t_a_off);
-      rc = apply_act(X.act(r.x0), nullptr, C, 0, B, S * S, X.at<float>(P->t_gn_off + r.ss_off), 2, 0u, 0u, 1.f, abuf, st);
-      if (rc) return rc;
+      float* abuf = X.at<float>(P->t_a_off);        // (the activated input, written by act_bwd's first pass)
       c.src0 = abuf; c.C0 = C; c.B = B; c.Hs = S; c.Ws = S; c.stride = 1; c.ksize = 3; c.Ho = S; c.Wo = S;
       c.Cout = 4;
       rc = wgrad_call(X, c, geps, dwtmp);
@@ -220,7 +231,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (r.act) {
         rc = act_bwd(dA, x0p, x1p, C0, C1, B, x0.H * x0.W, X.at<float>(P->t_gn_off + r.ss_off),
                      X.at<float>(P->t_misc_off + r.mr_off), G, r.act, params + r.gamma, part, gs, grads + r.gamma,
-                     grads + r.beta, d0, d1, st, lseed, dropped ? dc.thresh : 0u, dc.scale);
+                     grads + r.beta, d0, d1, st, lseed, dropped ? dc.thresh : 0u, dc.scale, X.at<float>(P->t_a_off));
       } else {
         rc = grad_route(dA, C0, C1, B, x0.H, x0.W, r.ups, d0, d1, st);
       }
@@ -231,11 +242,9 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       c.B = B; c.Hs = x0.H; c.Ws = x0.W; c.ups = r.ups; c.stride = r.stride;
       c.ksize = r.ksize; c.Ho = Ho; c.Wo = Wo; c.Cout = Cout;
       if (r.act) {
-        // the activated (and dropped) input is materialised once instead of being recomputed per tap
+        // the activated (and dropped) input is materialised once instead of being recomputed per tap: by act_bwd's first pass
+        // above (round 6; it was a pass of its own over x, k_apply_act)
         float* abuf = X.at<float>(P->t_a_off);
-        rc = apply_act(x0p, x1p, C0, C1, B, x0.H * x0.W, X.at<float>(P->t_gn_off + r.ss_off), r.act, lseed,
-                       dropped ? dc.thresh : 0u, dc.scale, abuf, st);
-        if (rc) return rc;
         c.src0 = abuf; c.C0 = Cin; c.C1 = 0;
       } else {
         c.src0 = x0p; c.src1 = x1p; c.C0 = C0; c.C1 = C1;
