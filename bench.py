@@ -48,7 +48,7 @@ PROFILE_ROUND = 'r06'
 # kernel), 575 = the two-workgroups-per-CU SPLIT kernel of conv3x3_wino2.hip; im2col SPLIT tiles 14-17
 WINO_KINDS = (455, 465, 555, 565, 575)
 WINO_SPLIT_KINDS = (555, 565, 575)
-IGEMM_SPLIT_KINDS = (651, 652, 653, 654)              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
+IGEMM_SPLIT_KINDS = (651, 652, 653, 654, 232)         # (232: the plain 1x1 GEMM kernel of gemm1x1.hip, plan option gemm2; round 6)              # profiles/<round>_hbm_traffic.json, <round>_sq_counters.json feed `roofline`
 
 # The `model` subtrees of the reference's configs (config/sr_sr3_16_128.json:39-77, sr_sr3_64_512.json:39-80,
 # sample_ddpm_128.json:38-79) + the batch sizes BASELINE.json quotes.

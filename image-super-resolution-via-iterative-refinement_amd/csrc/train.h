@@ -10,12 +10,15 @@ namespace sr3 {
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
             float* dx1, hipStream_t st, unsigned drop_seed = 0, unsigned drop_thresh = 0, float drop_scale = 1.f,
-            float* aout = nullptr);      // aout: also write a = dropout(act(x*scale+shift)) (what apply_act would, in the same pass; round 6)
+            float* aout = nullptr, bool acc0 = true, bool acc1 = true);      // aout: also write a = dropout(act(x*scale+shift)) (what apply_act would, in the same pass; round 6)
 // a = dropout(act(x*scale+shift)) over the virtual concat, materialised for the weight-gradient GEMM
 int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, int act, unsigned drop_seed,
               unsigned drop_thresh, float drop_scale, float* out, hipStream_t st);
 size_t act_bwd_part_bytes(int B, int HW, int C);
-int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st);
+// acc0 / acc1 (here and in act_bwd): false = the first contribution to that destination in the backward walk is a plain store (round 6:
+// the gradient mirror is no longer zeroed every step)
+int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st,
+               bool acc0 = true, bool acc1 = true);
 int zero_insert(const float* g, int B, int Ho, int Wo, int C, float* z, hipStream_t st);
 int w_flip_transpose(const float* w, int Cout, int taps, int Cin, int CoutP, float* wt, hipStream_t st);
 int colsums(const float* g, int B, int HW, int C, double* part, float* dbias, float* dfilm, int film_stride,

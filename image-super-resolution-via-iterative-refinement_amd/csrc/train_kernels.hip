@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
                                                        const float* __restrict__ mr, const double* __restrict__ gs,
                                                        int groups, const float* __restrict__ gamma,
                                                        float* __restrict__ dx0, float* __restrict__ dx1,
-                                                       size_t total4) {
+                                                       size_t total4, int acc0, int acc1) {
   const int C = C0 + C1;
   const int nq = C >> 2;
   const int cpg = C / groups;
@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
     const int Cs = second ? C1 : C0, cs = second ? c - C0 : c;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(du + pix * C + c);
     const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + pix * Cs + cs);
-    f32x4 o = *reinterpret_cast<const f32x4*>(ds + pix * Cs + cs);
+    // (acc == 0: this is the first contribution to that gradient tensor in the backward walk -- a plain store, the mirror is not zeroed)
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (second ? acc1 : acc0) o = *reinterpret_cast<const f32x4*>(ds + pix * Cs + cs);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int g = (c + e) / cpg;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(const float* __restrict__ 
 // 2x2 children of every source pixel (backward of the nearest x2 upsample, unet.py:61).
 __global__ __launch_bounds__(256) void k_grad_route(const float* __restrict__ g, int C0, int C1, int B, int Hs, int Ws,
                                                      int ups, float* __restrict__ d0, float* __restrict__ d1,
-                                                     size_t total4) {
+                                                     size_t total4, int acc0, int acc1) {
   const int C = C0 + C1;
   const int nq = C >> 2;
   const int Wg = Ws << ups;
@@ -222,8 +224,8 @@ __global__ __launch_bounds__(256) void k_grad_route(const float* __restrict__ g,
     } else {
       acc = *reinterpret_cast<const f32x4*>(g + pix * C + c);
     }
-    f32x4 o = *reinterpret_cast<const f32x4*>(ds + pix * Cs + cs);
-    o += acc;
+    f32x4 o = acc;
+    if (second ? acc1 : acc0) o += *reinterpret_cast<const f32x4*>(ds + pix * Cs + cs);
     *reinterpret_cast<f32x4*>(ds + pix * Cs + cs) = o;
   }
 }
@@ -392,7 +394,7 @@ static inline int ew_blocks(size_t n) { size_t b = (n + 255) / 256; return (int)
 
 int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, int HW, const float* ss, const float* mr,
             int groups, int act, const float* gamma, double* part, double* gs, float* dgamma, float* dbeta, float* dx0,
-            float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale, float* aout) {
+            float* dx1, hipStream_t st, unsigned drop_seed, unsigned drop_thresh, float drop_scale, float* aout, bool acc0, bool acc1) {
   const int C = C0 + C1;
   if ((C0 & 3) || (C1 & 3)) { set_error("act_bwd: channels %% 4"); return SR3_E_UNSUPPORTED; }
   int LQ, cblocks, ppb, T;
@@ -406,7 +408,7 @@ int act_bwd(float* dA, const float* x0, const float* x1, int C0, int C1, int B, 
   SR3_LAUNCH_CHECK("k_part_colsum");
   const size_t total4 = (size_t)B * HW * (C >> 2);
   hipLaunchKernelGGL(k_gn_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, st, dA, x0, x1, C0, C1, HW, mr, gs, groups,
-                     gamma, dx0, dx1, total4);
+                     gamma, dx0, dx1, total4, acc0 ? 1 : 0, acc1 ? 1 : 0);
   SR3_LAUNCH_CHECK("k_gn_bwd_apply");
   return SR3_OK;
 }
@@ -425,9 +427,9 @@ int apply_act(const float* x0, const float* x1, int C0, int C1, int B, int HW, c
   return SR3_OK;
 }
 
-int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st) {
+int grad_route(const float* g, int C0, int C1, int B, int Hs, int Ws, int ups, float* d0, float* d1, hipStream_t st, bool acc0, bool acc1) {
   const size_t total4 = (size_t)B * Hs * Ws * ((C0 + C1) >> 2);
-  hipLaunchKernelGGL(k_grad_route, dim3(ew_blocks(total4)), dim3(256), 0, st, g, C0, C1, B, Hs, Ws, ups, d0, d1, total4);
+  hipLaunchKernelGGL(k_grad_route, dim3(ew_blocks(total4)), dim3(256), 0, st, g, C0, C1, B, Hs, Ws, ups, d0, d1, total4, acc0 ? 1 : 0, acc1 ? 1 : 0);
   SR3_LAUNCH_CHECK("k_grad_route");
   return SR3_OK;
 }

@@ -13,6 +13,8 @@
 // gradients live in a mirror of the activation arena and are accumulated in stream order.
 #include <string.h>
 
+#include <vector>
+
 #include "plan_internal.h"
 #include "train.h"
 
@@ -113,8 +115,10 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
   double* lparts = X.at<double>(P->t_dwtmp_off);
   rc = l1_loss_grad(z, eps, B, P->out_ch, S * S, 4, grad_scale, P->loss_l2 != 0, geps, lparts, loss_out, st);
   if (rc) return rc;
-  // ---- zero the activation-gradient mirror and the FiLM gradient table ----
-  SR3_HIP(hipMemsetAsync(ws + P->t_act_bytes, 0, P->t_act_bytes, st));
+  // ---- the activation-gradient mirror is NOT zeroed (round 6: 1.5 ms per step): the first contribution to a tensor's gradient in this
+  // walk is a plain store (`first` below), later ones accumulate in stream order; the FiLM gradient table is zeroed ----
+  std::vector<char> seen(P->ttens.size(), 0);
+  auto first = [&](int h) { if (h < 0) return false; const bool f = !seen[h]; seen[h] = 1; return f; };
   float* dfilm = X.at<float>(P->t_dfilm_off);
   SR3_HIP(hipMemsetAsync(dfilm, 0, (size_t)B * P->F * sizeof(float), st));
 
@@ -141,7 +145,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (rc) return rc;
       rc = act_bwd(dA, X.act(r.x0), nullptr, C, 0, B, S * S, X.at<float>(P->t_gn_off + r.ss_off),
                    X.at<float>(P->t_misc_off + r.mr_off), G, 2, params + r.gamma, part, gs, grads + r.gamma,
-                   grads + r.beta, X.grad(r.x0), nullptr, st, 0u, 0u, 1.f, X.at<float>(P->t_a_off));
+                   grads + r.beta, X.grad(r.x0), nullptr, st, 0u, 0u, 1.f, X.at<float>(P->t_a_off), !first(r.x0), true);
       if (rc) return rc;
       ConvParams c;
       memset(&c, 0, sizeof(c));
@@ -154,6 +158,7 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
     } else if (r.kind == R_ATTN) {
       const Tensor& o = P->ttens[r.o];
       // dK / dV through per-query-block slabs in the backward's scratch region, summed in block order: no atomics (round 6)
+      if (!first(r.qkv)) { set_error("train: the qkv gradient has an earlier writer"); return SR3_E_UNSUPPORTED; }     // (attention_backward stores)
       rc = attention_backward(X.act(r.qkv), X.grad(r.o), X.act(r.o), B, o.H * o.W, o.C, X.grad(r.qkv), st,
                               X.at<float>(P->t_scratch_off), P->t_scratch_bytes);
       if (rc) return rc;
@@ -196,8 +201,9 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       }
       // 2. identity residual
       if (r.r0 >= 0) {
+        const bool a0 = !first(r.r0), a1 = !first(r.r1);
         rc = grad_route(g, P->ttens[r.r0].C, r.r1 >= 0 ? P->ttens[r.r1].C : 0, B, Ho, Wo, 0, X.grad(r.r0),
-                        r.r1 >= 0 ? X.grad(r.r1) : nullptr, st);
+                        r.r1 >= 0 ? X.grad(r.r1) : nullptr, st, a0, a1);
         if (rc) return rc;
       }
       // 3. fused res_conv segment
@@ -206,7 +212,8 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
         float* dq = X.at<float>(P->t_dq_off);
         rc = dgrad_conv(X, g, Cout, Ho, Wo, 1, params + r.qw, Cout, Q0 + Q1, dq);
         if (rc) return rc;
-        rc = grad_route(dq, Q0, Q1, B, Ho, Wo, 0, X.grad(r.q0), r.q1 >= 0 ? X.grad(r.q1) : nullptr, st);
+        const bool a0 = !first(r.q0), a1 = !first(r.q1);
+        rc = grad_route(dq, Q0, Q1, B, Ho, Wo, 0, X.grad(r.q0), r.q1 >= 0 ? X.grad(r.q1) : nullptr, st, a0, a1);
         if (rc) return rc;
         ConvParams c;
         memset(&c, 0, sizeof(c));
@@ -228,12 +235,13 @@ int run_train(sr3_plan* P, const float* hr, const float* cond, int cond_channels
       if (rc) return rc;
       const bool dropped = r.has_drop && dc.thresh != 0;
       const unsigned lseed = drop_layer_seed(dc.seed, r.drop_key);
+      const bool acc0 = !first(r.x0), acc1 = !first(r.x1);
       if (r.act) {
         rc = act_bwd(dA, x0p, x1p, C0, C1, B, x0.H * x0.W, X.at<float>(P->t_gn_off + r.ss_off),
                      X.at<float>(P->t_misc_off + r.mr_off), G, r.act, params + r.gamma, part, gs, grads + r.gamma,
-                     grads + r.beta, d0, d1, st, lseed, dropped ? dc.thresh : 0u, dc.scale, X.at<float>(P->t_a_off));
+                     grads + r.beta, d0, d1, st, lseed, dropped ? dc.thresh : 0u, dc.scale, X.at<float>(P->t_a_off), acc0, acc1);
       } else {
-        rc = grad_route(dA, C0, C1, B, x0.H, x0.W, r.ups, d0, d1, st);
+        rc = grad_route(dA, C0, C1, B, x0.H, x0.W, r.ups, d0, d1, st, acc0, acc1);
       }
       if (rc) return rc;
       // 5. weight gradient
