@@ -95,7 +95,8 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm_wpre", "gemm_tile", "wgrad_split", "attn_split", "loss_l2"};
+ * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
+ * "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
  *   split instantiation: every fp32 operand as x = h + m + l (three bf16 terms, each residual exact in fp32), every product as
@@ -114,6 +115,15 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   maps >= 16 wide in an inference plan, block1 / Upsample convs and the data gradients in a training plan -- run as TWO independent
  *   four-wave workgroups per CU on an 8 x 16 pixel tile (conv3x3_wino2.hip; reported as tile 13): same arithmetic and derived filters,
  *   a wave owns one transform column and all four rows.  0: the 8-wave kernel of conv3x3_wino.hip everywhere (tile 12).
+ * gemm2 (default 1, round 6; needs gemm_split): 1x1 stride-1 convolutions with Cout % 128 == 0, channel counts % 32 == 0 and
+ *   B * H * W % 64 == 0 (res_conv, attention qkv / out of the BASELINE networks) run as a plain GEMM on the same 3 x bf16 split
+ *   arithmetic (gemm1x1.hip; reported as tile 22): 64 x 128 tile, weights pre-split in MFMA fragment order in the derived buffer
+ *   (6 bytes per weight: sr3_plan_derived_bytes grows; re-bind after toggling) and read straight from global memory, the A rows
+ *   split once per 128 output channels; a training plan's 1x1 data gradients use it too.  0: the im2col kernel (tiles 14-17).
+ * fold_fuse (default 1, round 6): the GroupNorm fold of a consumer is done by the kernel that completes its last source where that
+ *   is a split-K reduce or a stand-alone statistics pass (one workgroup per (image, consumer group), no atomics): those fold
+ *   launches leave the launch list (sr3_plan_num_ops shrinks), the conv outputs are bit-identical, the folded (scale, shift) pairs
+ *   differ in the order of their double-precision sums only.  0: every fold is a launch of its own.
  * gemm_wpre (default 0): the im2col split tiles read their weights pre-split AND in MFMA fragment order straight from the derived
  *   buffer (tiles 18-21; round 6's form, no LDS staging of the weights) instead of splitting them while staging (14-17, what a plan
  *   runs); measured slower in every layout tried (profiles/r05c_*, profiles/r06_gemm_wpre_fragment_major.txt), kept as an A/B knob.
@@ -274,8 +284,10 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * instantiation with both operands split while they are staged (what plan option gemm_split selects: what a plan runs), 18-21 =
  * the same with the weights pre-split into bf16 planes in MFMA fragment order and read straight from global memory (plan option
  * gemm_wpre, default off: a plan keeps the planes in its derived buffer; this entry point derives them into `scratch`; results
- * are bit-identical to 14-17).
- * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-21), sized by
+ * are bit-identical to 14-17); 22 = the plain GEMM kernel of gemm1x1.hip (what plan option gemm2 -- default on -- selects: 1x1
+ * stride 1, no upsampling, Cout % 128 == 0, C0 and C1 % 32 == 0, B * H * W % 64 == 0, H * W % 32 == 0, act 0 | 1; anything else
+ * is refused with "does not fit"; same pre-split weights as 18-21, derived into `scratch`).
+ * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-22), sized by
  * sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,
                  int stride, int ksize, int Cout, const float* w_ohwi, const float* bias, const float* ss,
