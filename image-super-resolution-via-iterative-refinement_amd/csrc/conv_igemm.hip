@@ -527,9 +527,12 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   if (tile_cfg == 22) {
     // 1x1 GEMM kernel (gemm1x1.hip; two workgroups per CU): split K below one round of workgroups, >= 4 k-steps (128 channels) per split
     if (ksplit == 0) {
-      const long tiles = (long)(M / 64) * (p.Cout / 128);
+      const long tiles = (long)(M / gemm1x1_rows(p)) * (p.Cout / 128);
       int ks = 1;
-      if (tiles < 128 && tiles > 0) {
+#ifndef SR3_G1_SPLIT_BELOW
+#define SR3_G1_SPLIT_BELOW 128
+#endif
+      if (tiles < SR3_G1_SPLIT_BELOW && tiles > 0) {
         ks = (int)((512 + tiles - 1) / tiles);
         const int cap = nchunks / 4 > 1 ? nchunks / 4 : 1;
         if (ks > cap) ks = cap;

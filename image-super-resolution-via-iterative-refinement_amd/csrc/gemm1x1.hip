@@ -295,13 +295,29 @@ bool gemm1x1_fits(const ConvParams& p, int mi) {
          M % (32 * mi) == 0 && ((p.Ho * p.Wo) & 31) == 0 && (p.act == 0 || p.act == 1) && p.drop_thresh == 0 && !p.x2_w;
 }
 
+// rows of the tile: 64 (two m blocks per wave), or 32 where 64 would leave workgroup slots empty -- 512 slots = two workgroups per CU; the
+// N = 512 layers at 16 x 16 (M = 4096) give 256 tiles of 64 rows: one wave per SIMD, nothing to overlap with; 512 tiles of 32 rows fill them
+int gemm1x1_rows(const ConvParams& p) {
+#ifdef SR3_G1_NO32
+  return 64;
+#else
+  // measured in the C2 forward (profiles/r06_gemm1x1.txt, item 7): 512 -> 512 at 16 x 16 29 -> 25.6 us and the 8 x 8 maps' layers
+  // without split-K (18.6 / 22.3 us against 21.2 / 25.5 with it) gain; 1024 -> 512 and 768 -> 512 at 16 x 16 lose 1-2 us (long K: the
+  // 64-row tile's reuse of the weight fragments wins), so they keep 64 rows
+  const long M = (long)p.B * p.Ho * p.Wo;
+  if ((M / 64) * (p.Cout / 128) >= 384) return 64;
+  return (M <= 1024 || p.C0 + p.C1 <= 512) ? 32 : 64;
+#endif
+}
+
 int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   if (!gemm1x1_fits(p, mi) || !p.w_split) { set_error("conv: the 1x1 GEMM kernel (tile 22 / 23) does not fit this problem"); return SR3_E_UNSUPPORTED; }
   if (p.act == 1 && !p.ss) { set_error("conv: act needs ss"); return SR3_E_BADARG; }
   const int M = p.B * p.Ho * p.Wo;
+  mi = gemm1x1_rows(p) / 32;
   dim3 grid((M / (32 * mi)) * (p.Cout / 128), p.ksplit);
   const int smem = 2 * 2 * mi * 3 * 1024;
-  static std::atomic<uint64_t> done[2];
+  static std::atomic<uint64_t> done[4];
   auto go = [&](auto kern, std::atomic<uint64_t>& d) -> int {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, d)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
@@ -311,6 +327,7 @@ int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   // (MI = 4, a 128-row tile with half the weight traffic per row, was built and dropped: at 256 registers it spills, and the weight
   // traffic is not what bounds this kernel -- profiles/r06_gemm1x1.txt)
   if (mi == 2) return p.act ? go(k_gemm1x1_split<2, true>, done[0]) : go(k_gemm1x1_split<2, false>, done[1]);
+  if (mi == 1) return p.act ? go(k_gemm1x1_split<1, true>, done[2]) : go(k_gemm1x1_split<1, false>, done[3]);
   set_error("conv: bad 1x1 GEMM tile");
   return SR3_E_BADARG;
 }

@@ -221,6 +221,7 @@ int igemm_split_weights(const float* w, int Cout, int taps, int Cin, float* out,
 // 1x1 stride-1 convs as a plain GEMM on the split arithmetic (gemm1x1.hip; tile_cfg 22: 64 x 128 tile, mi = 2; needs w_split)
 bool gemm1x1_fits(const ConvParams& p, int mi);
 int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st);
+int gemm1x1_rows(const ConvParams& p);      // 64, or 32 where 64-row tiles would leave workgroup slots empty
 // profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the
 // split-K reduce kernel (then resets the pointer).  Thread-local.
 void conv_set_mid_event(hipEvent_t ev);

@@ -164,10 +164,11 @@ def test_plan_launch_list_no_gpu():
     # plan option fold_fuse (default 1, round 6): 31 of the 61 GroupNorm folds are done by the kernel that completes their (last) source --
     # the split-K reduce of the conv in front of them, or the stand-alone statistics pass -- and leave the launch list
     fops = p.op_list(16)
-    assert len(fops) == p.num_ops(16) == 137 and sum(1 for o in fops if o['kind'] == 40) == 30
+    assert len(fops) == p.num_ops(16) == 138 and sum(1 for o in fops if o['kind'] == 40) == 30
+    assert sum(1 for o in fops if o['kind'] == 30) == 7       # (the 8x8 attention's out conv runs unsplit on the 32-row tile: a statistics pass, which folds)
     assert [o for o in fops if o['kind'] != 40] == [o for o in (p.set_option('fold_fuse', 0), p.op_list(16))[1] if o['kind'] != 40]
     wops = p.op_list(16)                               # (the rest of this test walks the other options with fold_fuse off)
-    assert len(wops) == p.num_ops(16) == 168      # (round 3: the input conv writes its own GroupNorm partials: no statistics pass)
+    assert len(wops) == p.num_ops(16) == 169      # (168 + the statistics pass behind the unsplit 8x8 out conv of gemm2; round 3: the input conv writes its own GroupNorm partials: no statistics pass)
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     # plan option gemm2 (default 1, round 6): the 1x1 stride-1 convs with Cout % 128 == 0 run the plain GEMM kernel of gemm1x1.hip
     # (tile 22; rows % 64 == 0 and channels % 32 == 0 hold for every layer of this network), reading their weights pre-split in MFMA
@@ -175,15 +176,18 @@ def test_plan_launch_list_no_gpu():
     dconvs = [o for o in wops if o['kind'] == 50]
     for o in dconvs:
         assert (o['tile_cfg'] == 22) == (o['ksize'] == 1 and o['stride'] == 1 and o['cout'] % 128 == 0), o
-        if o['tile_cfg'] == 22:        # split-K only below 128 workgroups (the 8x8 maps with Cout = 512)
-            assert (o['ksplit'] > 1) == ((16 * o['h_out'] * o['w_out'] // 64) * (o['cout'] // 128) < 128), o
+        if o['tile_cfg'] == 22:        # split-K only below 128 workgroups; tile rows 64, or 32 where 64-row tiles leave slots empty (gemm1x1_rows)
+            M = 16 * o['h_out'] * o['w_out']
+            rows = 64 if (M // 64) * (o['cout'] // 128) >= 384 else (32 if (M <= 1024 or o['cin'] <= 512) else 64)
+            assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // 128) < 128), o
     assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 27
     nbytes_gemm2 = int(p.lib.sr3_plan_derived_bytes(p.handle))
     p.set_option('gemm2', 0)           # the rest of this test walks the im2col options with gemm2 off
     assert nbytes_gemm2 - int(p.lib.sr3_plan_derived_bytes(p.handle)) == 6 * sum(o['cout'] * o['cin'] for o in dconvs if o['tile_cfg'] == 22)
     wops0 = p.op_list(16)
-    for a, b in zip(wops, wops0):
-        assert a['kind'] == b['kind'] and a['flops'] == b['flops'] and (a['tile_cfg'] == b['tile_cfg'] or (a['tile_cfg'] == 22 and b['tile_cfg'] == 16))
+    assert len(wops0) == p.num_ops(16) == 168
+    for a, b in zip([o for o in wops if o['kind'] == 50], [o for o in wops0 if o['kind'] == 50]):
+        assert a['flops'] == b['flops'] and (a['tile_cfg'] == b['tile_cfg'] or (a['tile_cfg'] == 22 and b['tile_cfg'] == 16))
     wops = wops0
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:
