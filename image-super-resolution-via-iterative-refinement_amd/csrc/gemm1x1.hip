@@ -7,15 +7,17 @@
 //
 // What is different from conv_igemm.hip's SPLITM = 1 / 2 forms (the measurements that led here: profiles/r04f_gemm_split_sweep.txt,
 // r06_gemm_wpre_fragment_major.txt -- those kernels are bound by VALU work per MFMA: ~150-300 VALU instructions per 12 MFMAs):
-//  * tile 32*MI (M) x 128 (N), four waves side by side along N: every wave owns ONE 32-column block and all the rows, so its
-//    B fragments (the pre-split weights in MFMA fragment order, igemm_split_weights) are its own -- read straight from global
-//    memory into registers two k-steps ahead, no LDS, no redundant fetch inside the workgroup;
+//  * tile 32*MI (M) x 128 (N), MI = 2 (64 rows; 32 where that would leave workgroup slots empty: gemm1x1_rows), four waves side by side
+//    along N: every wave owns ONE 32-column block and all the rows, so its B fragments (the pre-split weights in MFMA fragment order,
+//    igemm_split_weights) are its own -- read straight from global memory into registers two k-steps ahead, no LDS, no redundant fetch
+//    inside the workgroup;
 //  * the A rows are loaded two k-steps ahead, split once per workgroup and written to LDS in FRAGMENT order ([K = 16 step][m block]
 //    [plane][lane][8 bf16]): a fragment read is base + lane * 16, conflict-free without a swizzle; one barrier per k-step, two stages;
-//  * per k-step and wave: MI * 12 MFMAs against 8 * MI / 2 ... = 4 * MI split elements per lane (~ 7 VALU each with the affine):
-//    2.3 VALU per MFMA, under the ~5 plain VALU an MFMA hides when they are interleaved (profiles/r05a_mfma_fillers.txt) -- the split
-//    is the `v_dot2c`-free one here (plain VALU only) and the staging arithmetic is placed between the MFMAs with sched_group_barrier;
+//  * per k-step and wave: MI * 12 MFMAs against 4 * MI split elements per lane: ~3 plain VALU per MFMA, under the ~5 an MFMA hides when
+//    they are interleaved (profiles/r05a_mfma_fillers.txt) -- the split is the `v_dot2c`-free one here (plain VALU only) and the staging
+//    arithmetic is cut into slices placed by hand between the MFMAs (sched_barrier(0) pins every (MFMA, slice) group; see `step`);
 //  * loop state is pointer increments (no division, no bounds: the host checks M % BM == 0, Cout % 128 == 0, channels % 32 == 0).
+// What bounds it, and the scheduling variants that changed nothing: profiles/r06_gemm1x1.txt, DESIGN.md section 3.1g.
 #include <stdlib.h>
 
 #include "sr3_common.h"
@@ -300,6 +302,8 @@ bool gemm1x1_fits(const ConvParams& p, int mi) {
 int gemm1x1_rows(const ConvParams& p) {
 #ifdef SR3_G1_NO32
   return 64;
+#elif defined(SR3_G1_ALL32)
+  return 32;
 #else
   // measured in the C2 forward (profiles/r06_gemm1x1.txt, item 7): 512 -> 512 at 16 x 16 29 -> 25.6 us and the 8 x 8 maps' layers
   // without split-K (18.6 / 22.3 us against 21.2 / 25.5 with it) gain; 1024 -> 512 and 768 -> 512 at 16 x 16 lose 1-2 us (long K: the
@@ -311,7 +315,7 @@ int gemm1x1_rows(const ConvParams& p) {
 }
 
 int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
-  if (!gemm1x1_fits(p, mi) || !p.w_split) { set_error("conv: the 1x1 GEMM kernel (tile 22 / 23) does not fit this problem"); return SR3_E_UNSUPPORTED; }
+  if (!gemm1x1_fits(p, mi) || !p.w_split) { set_error("conv: the 1x1 GEMM kernel (tile 22) does not fit this problem"); return SR3_E_UNSUPPORTED; }
   if (p.act == 1 && !p.ss) { set_error("conv: act needs ss"); return SR3_E_BADARG; }
   const int M = p.B * p.Ho * p.Wo;
   mi = gemm1x1_rows(p) / 32;
