@@ -225,13 +225,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(const ConvParams p,
     const float* sp = second ? p.src1 : p.src0;
     const int sC = second ? p.C1 : p.C0;
     const int cs = second ? ce - p.C0 : ce;
+    // power-of-two maps at least PX wide: the unit's PX pixels lie in one image row -- decode the first, step the column (round 6: the
+    // per-pixel decode was a third of this kernel's 6 VALU instructions per MFMA)
+    int ub = 0, uoh = 0, uow = 0;
+    const bool rowunit = logW >= 3 && PX == 8;
+    if (rowunit) {
+      const int m0 = min(chunk * 32 + ug * PX, M - PX);
+      ub = m0 >> logHW;
+      const int rem = m0 & (HoWo - 1);
+      uoh = rem >> logW; uow = rem & (p.Wo - 1);
+    }
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
       const int m = chunk * 32 + ug * PX + i;
       const bool mv = m < M;
       const int me = mv ? m : 0;
       int b, oh, ow;
-      if (logW >= 0) {
+      if (rowunit) {
+        b = ub; oh = uoh; ow = uow + i;
+      } else if (logW >= 0) {
         b = me >> logHW;
         const int rem = me & (HoWo - 1);
         oh = rem >> logW; ow = rem & (p.Wo - 1);
@@ -274,10 +286,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(const ConvParams p,
     // k position of the unit's pixels inside the chunk: pixel index ug * PX + i = 16 ks + 8 kh + e
     const int p0 = ug * PX;
     const int ks = p0 >> 4, kh = (p0 >> 3) & 1, e0 = p0 & 7;          // (PX = 8: e0 = 0; PX = 4: e0 = 0 or 4)
-    const int row0 = (is_act ? TN : 0) + uq * 4;
+    // fragment row of channel 4 uq + chn = chn * QUADS + uq (round 6): the lanes of a write -- consecutive uq -- hit consecutive 16-byte rows
+    // (row 4 uq + chn put them 64 bytes apart: four-way bank conflicts, 60 % of the kernel's LDS cycles); the epilogue un-permutes
+    const int row0 = (is_act ? TN : 0) + uq;
 #pragma unroll
     for (int chn = 0; chn < 4; ++chn) {
-      __bf16* dstp = planes + ((size_t)(ks * 2 + kh) * ROWS + row0 + chn) * 8 + e0;
+      __bf16* dstp = planes + ((size_t)(ks * 2 + kh) * ROWS + row0 + chn * QUADS) * 8 + e0;
       if constexpr (PX == 8) {
         const f32x4 lo = {v[0][chn], v[1][chn], v[2][chn], v[3][chn]}, hi = {v[4][chn], v[5][chn], v[6][chn], v[7][chn]};
         bf16x8 h, m, l;
@@ -343,10 +357,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad_split(const ConvParams p,
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int c = tile_c * TC + wave_c * WC + 32 * j + (lane & 31);
+      const int cr = wave_c * WC + 32 * j + (lane & 31);                       // fragment row -> channel: 4 (row % QUADS) + row / QUADS
+      const int c = tile_c * TC + 4 * (cr % QUADS) + cr / QUADS;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = tile_n * TN + wave_n * WN + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int nr = wave_n * WN + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = tile_n * TN + 4 * (nr % QUADS) + nr / QUADS;
         if (n < p.Cout && c < Cin) dst[((size_t)n * taps + tap) * Cin + c] = acc[i][j][r];
       }
     }
