@@ -498,8 +498,17 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     // double accumulation: a batch can hold samples whose gradient terms are orders of magnitude larger than the
     // others' (noise levels near 0); summing their slabs with the rest in fp32 costs the small ones their low bits
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int s = 0; s < msplit; ++s) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + ((size_t)s * n4 + i) * 4);
+    auto slab = [&](int s) { return *reinterpret_cast<const f32x4*>(slabs + ((size_t)s * n4 + i) * 4); };
+    int s = 0;
+    for (; s + 4 <= msplit; s += 4) {      // four slabs in flight (same order of additions; one load per iteration waited for each in turn)
+      const f32x4 v0 = slab(s), v1 = slab(s + 1), v2 = slab(s + 2), v3 = slab(s + 3);
+      a0 += (double)v0.x; a1 += (double)v0.y; a2 += (double)v0.z; a3 += (double)v0.w;
+      a0 += (double)v1.x; a1 += (double)v1.y; a2 += (double)v1.z; a3 += (double)v1.w;
+      a0 += (double)v2.x; a1 += (double)v2.y; a2 += (double)v2.z; a3 += (double)v2.w;
+      a0 += (double)v3.x; a1 += (double)v3.y; a2 += (double)v3.z; a3 += (double)v3.w;
+    }
+    for (; s < msplit; ++s) {
+      const f32x4 v = slab(s);
       a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
     }
     const f32x4 r = {(float)a0, (float)a1, (float)a2, (float)a3};
