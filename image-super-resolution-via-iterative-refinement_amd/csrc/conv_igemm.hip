@@ -532,13 +532,20 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
 #ifndef SR3_G1_SPLIT_BELOW
 #define SR3_G1_SPLIT_BELOW 128
 #endif
-      if (tiles < SR3_G1_SPLIT_BELOW && tiles > 0) {
+#ifndef SR3_G1_S2_SPLIT_BELOW
+#define SR3_G1_S2_SPLIT_BELOW 512
+#endif
+      // the stride-2 form walks 9 k-steps per 32-channel chunk: K is long (>= 36 steps at 128 channels) and the maps are small, so it
+      // splits whenever the tiles do not fill the 512 slots, >= 8 k-steps per split
+      const int ksteps = nchunks * taps;
+      const int below = taps == 9 ? SR3_G1_S2_SPLIT_BELOW : SR3_G1_SPLIT_BELOW;
+      if (tiles < below && tiles > 0) {
         ks = (int)((512 + tiles - 1) / tiles);
-        const int cap = nchunks / 4 > 1 ? nchunks / 4 : 1;
+        const int cap = taps == 9 ? (ksteps / 8 > 1 ? ksteps / 8 : 1) : (nchunks / 4 > 1 ? nchunks / 4 : 1);
         if (ks > cap) ks = cap;
         if (ks > 16) ks = 16;
       }
-      while (ks > 1 && (long)(ks - 1) * cdiv(nchunks, ks) >= nchunks) --ks;
+      while (ks > 1 && (long)(ks - 1) * cdiv(ksteps, ks) >= ksteps) --ks;
       ksplit = ks;
     }
     return;

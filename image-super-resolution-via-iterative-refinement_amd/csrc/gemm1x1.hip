@@ -49,8 +49,14 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 }  // namespace
 
-template <int MI, bool ACT>
+// S2 (round 6, last session): the same GEMM over the 9 taps of a 3x3 stride-2 pad-1 convolution (Downsample, unet.py:58-64: a bare conv,
+// no norm in front) -- k-step `it` = (32-channel chunk, tap) in the order igemm_split_weights lays the fragments out (it = chunk * 9 + tap),
+// the A row of output pixel (b, oh, ow) for tap (ky, kx) is the NHWC row of input pixel (2 oh + ky - 1, 2 ow + kx - 1): a per-step uniform
+// offset added to the row's base address.  Padding touches only the top row / left column of the map (even H, W): those rows load the
+// centre pixel instead (an address select, no branch) and are zeroed where the staged value is picked up.
+template <int MI, bool ACT, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
+  static_assert(!(ACT && S2), "the stride-2 form has no GroupNorm affine");
   constexpr int BM = 32 * MI;
   constexpr int FRAG = 64 * 16;                 // bytes of one operand fragment (64 lanes x 8 bf16)
   constexpr int STAGE = 2 * MI * 3 * FRAG;      // [K = 16 step 2][m block MI][plane 3][FRAG]
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   const int Cin = p.C0 + p.C1;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
-  const int total = Cin >> 5;
+  const int total = (Cin >> 5) * (S2 ? 9 : 1);
   const int per = (total + p.ksplit - 1) / p.ksplit;
   const int it0 = blockIdx.y * per;
   const int it1 = min(total, it0 + per);
@@ -80,11 +86,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   // ---- loaders ---------------------------------------------------------------------------------
   const int kq = tid & 7, lrow = tid >> 3;
   int aoff0[MI], aoff1[MI], ssoff[MI];
+  int edge[MI];          // S2: bit 0 = output row 0 (tap row ky = 0 is padding), bit 1 = output column 0 (kx = 0 is padding)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = tile_m * BM + lrow + 32 * i;
-    aoff0[i] = m * p.C0 + kq * 4;
-    aoff1[i] = m * p.C1 + kq * 4 - p.C0;       // + c gives the offset inside src1 for c >= C0
+    if constexpr (S2) {
+      const int b = m / HoWo, r = m - b * HoWo;
+      const int oh = r / p.Wo, ow = r - oh * p.Wo;
+      aoff0[i] = ((b * p.Hs + 2 * oh) * p.Ws + 2 * ow) * p.C0 + kq * 4;      // the centre tap's pixel
+      aoff1[i] = 0;
+      edge[i] = (oh == 0 ? 1 : 0) | (ow == 0 ? 2 : 0);
+    } else {
+      aoff0[i] = m * p.C0 + kq * 4;
+      aoff1[i] = m * p.C1 + kq * 4 - p.C0;       // + c gives the offset inside src1 for c >= C0
+      edge[i] = 0;
+    }
     ssoff[i] = ((m / HoWo) * Cin + kq * 4) * 2;
   }
   const bf16x8* bq = reinterpret_cast<const bf16x8*>(p.w_split) + ((size_t)(tile_n * 4 + wave) * total + it0) * (6 * 64) + lane;
@@ -92,7 +108,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   f32x4 ra[3][MI];
   bf16x8 rb[3][6];
   f32x4 ssa[MI], ssb[MI];
+  int pad[3] = {0, 0, 0};       // S2: bit i = row i of register set s is padding (its staged value is zero)
   auto load_a = [&](int s, int it) {
+    if constexpr (S2) {
+      const int chunk = it / 9, tap = it - chunk * 9;        // wave-uniform
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int off = ((ky - 1) * p.Ws + (kx - 1)) * p.C0 + (chunk << 5);
+      const int tapedge = (ky == 0 ? 1 : 0) | (kx == 0 ? 2 : 0);
+      int pm = 0;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bool out = (edge[i] & tapedge) != 0;
+        ra[s][i] = *reinterpret_cast<const f32x4*>(p.src0 + aoff0[i] + (out ? (chunk << 5) : off));
+        pm |= out ? (1 << i) : 0;
+      }
+      pad[s] = pm;
+      return;
+    }
     const int c = it << 5;
     const bool second = c >= p.C0;          // wave-uniform
     const float* sp = second ? p.src1 : p.src0;
@@ -122,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       f32x4 v = ra[s][i];
+      if constexpr (S2) { if (pad[s] & (1 << i)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
       if constexpr (ACT) {
         v.x = opaque(fmaf(v.x, ssa[i].x, ssa[i].y));
         v.y = opaque(fmaf(v.y, ssa[i].z, ssa[i].w));
@@ -187,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
       const int j = sl / NSQ, ph = sl % NSQ;
       if (ph == 0) {
         v[j] = ra[s1][j];
+        if constexpr (S2) { if (pad[s1] & (1 << j)) v[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         if constexpr (ACT) {
           v[j].x = opaque(fmaf(v[j].x, ssa[j].x, ssa[j].y));
           v[j].y = opaque(fmaf(v[j].y, ssa[j].z, ssa[j].w));
@@ -291,9 +325,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   }
 }
 
+bool gemm1x1_s2(const ConvParams& p) {      // the 3x3 stride-2 pad-1 form (Downsample): one source, no activation, even map
+  return p.ksize == 3 && p.stride == 2 && p.C1 == 0 && p.act == 0 && !(p.Hs & 1) && !(p.Ws & 1) && p.Ho * 2 == p.Hs && p.Wo * 2 == p.Ws;
+}
 bool gemm1x1_fits(const ConvParams& p, int mi) {
   const long M = (long)p.B * p.Ho * p.Wo;
-  return p.ksize == 1 && p.stride == 1 && p.ups == 0 && (p.Cout & 127) == 0 && p.C0 > 0 && (p.C0 & 31) == 0 && (p.C1 & 31) == 0 &&
+  return ((p.ksize == 1 && p.stride == 1) || gemm1x1_s2(p)) && p.ups == 0 && (p.Cout & 127) == 0 && p.C0 > 0 && (p.C0 & 31) == 0 && (p.C1 & 31) == 0 &&
          M % (32 * mi) == 0 && ((p.Ho * p.Wo) & 31) == 0 && (p.act == 0 || p.act == 1) && p.drop_thresh == 0 && !p.x2_w;
 }
 
@@ -310,6 +347,7 @@ int gemm1x1_rows(const ConvParams& p) {
   // 64-row tile's reuse of the weight fragments wins), so they keep 64 rows
   const long M = (long)p.B * p.Ho * p.Wo;
   if ((M / 64) * (p.Cout / 128) >= 384) return 64;
+  if (p.ksize == 3) return 32;       // (stride-2 form: long K, few rows -- 32-row tiles and split-K fill the slots, conv_pick)
   return (M <= 1024 || p.C0 + p.C1 <= 512) ? 32 : 64;
 #endif
 }
@@ -321,7 +359,7 @@ int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   mi = gemm1x1_rows(p) / 32;
   dim3 grid((M / (32 * mi)) * (p.Cout / 128), p.ksplit);
   const int smem = 2 * 2 * mi * 3 * 1024;
-  static std::atomic<uint64_t> done[4];
+  static std::atomic<uint64_t> done[6];
   auto go = [&](auto kern, std::atomic<uint64_t>& d) -> int {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, d)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
@@ -330,6 +368,10 @@ int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   };
   // (MI = 4, a 128-row tile with half the weight traffic per row, was built and dropped: at 256 registers it spills, and the weight
   // traffic is not what bounds this kernel -- profiles/r06_gemm1x1.txt)
+  if (p.ksize == 3) {
+    if (p.act) { set_error("conv: the stride-2 form of the GEMM kernel takes no activation"); return SR3_E_UNSUPPORTED; }
+    return mi == 2 ? go(k_gemm1x1_split<2, false, true>, done[4]) : go(k_gemm1x1_split<1, false, true>, done[5]);
+  }
   if (mi == 2) return p.act ? go(k_gemm1x1_split<2, true>, done[0]) : go(k_gemm1x1_split<2, false>, done[1]);
   if (mi == 1) return p.act ? go(k_gemm1x1_split<1, true>, done[2]) : go(k_gemm1x1_split<1, false>, done[3]);
   set_error("conv: bad 1x1 GEMM tile");

@@ -451,7 +451,7 @@ struct Builder {
       conv_pick(c, o.tile_cfg, o.ksplit);
     }
     if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->gemm2 && P->tile_cfg == 0 && P->gemm_tile == 0 && P->wsplit_of.count(w)) {
-      // plan option gemm2: 1x1 stride-1 convs the plain GEMM kernel fits (gemm1x1.hip)
+      // plan option gemm2: 1x1 stride-1 convs -- and Downsample's 3x3 stride-2 ones -- the plain GEMM kernel fits (gemm1x1.hip)
       if (gemm1x1_fits(c, 2)) {
         o.tile_cfg = 22; o.ksplit = P->ksplit;
         conv_pick(c, o.tile_cfg, o.ksplit);
@@ -677,7 +677,7 @@ void layout_derived(sr3_plan* P) {
   if (P->gemm_split && (P->gemm_wpre || P->gemm2)) {
     auto regw = [&](size_t w, int Cout, int taps, int Cin) {
       if (Cin & 3) return;
-      if (!P->gemm_wpre && (taps != 1 || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take
+      if (!P->gemm_wpre && ((taps != 1 && taps != 9) || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take (1x1; Downsample's 3x3 stride 2)
       P->wsplits.push_back({w, Cout, taps, Cin, dcur});
       P->wsplit_of[w] = dcur;
       dcur += igemm_wsplit_floats(Cout, taps, Cin);

@@ -3,6 +3,7 @@ same arguments), with the per-sample float transform moved onto the MI355X: the 
 batches, DeviceBatches turns each into the reference's batch dict ({'HR', 'SR', ['LR'], 'Index'}: fp32 NCHW in
 [-1, 1]) already resident on the device, which DDPM.feed_data then takes as is.'''
 import logging
+import os
 
 import torch
 import torch.utils.data
@@ -47,7 +48,10 @@ class DeviceBatches(object):
         _, world = _dp()
         from sr3_hip.dist import dp_active, val_chain_batch
         chain = val_chain_batch() if self.deal_waves else 1
-        if not (self.deal_waves and (dp_active() or chain > 1)):
+        # (SR3_VAL_ITEM_STREAMS=1 set explicitly: one-item waves too, so a one-chain-per-image run draws the per-item streams a
+        # batched run draws -- the comparison the streams exist for; unset, a plain batch-1 run keeps the default generator)
+        force = self.deal_waves and os.environ.get('SR3_VAL_ITEM_STREAMS') == '1'
+        if not (self.deal_waves and (dp_active() or chain > 1 or force)):
             yield from self._device_batches()
             return
         # validation: every rank walks ALL items in order, `world * chain` at a time; the wave object lets DDPM.test run the
@@ -55,9 +59,10 @@ class DeviceBatches(object):
         from sr3_hip.dist import ValWave
         world = world if dp_active() else 1
         group = []
+        first = 0                     # index of group[0] in this pass over the validation set: item k draws stream k in every pass
 
         def flush():
-            wave = ValWave([b['SR'] for b in group])
+            wave = ValWave([b['SR'] for b in group], first_item=first)
             for pos, b in enumerate(group):
                 b['_dp_wave'], b['_dp_pos'] = wave, pos
                 yield b
@@ -65,6 +70,7 @@ class DeviceBatches(object):
             group.append(b)
             if len(group) == world * chain:
                 yield from flush()
+                first += len(group)
                 group = []
         if group:
             yield from flush()

@@ -168,27 +168,41 @@ class EngineDiffusion(nn.Module):
         return out
 
     # ---- the reverse loop ------------------------------------------------------------------------
-    def _loop_state(self, shape, cond_shape, dev):
+    def _loop_state(self, shape, cond_shape, dev, item_streams=False):
         # a captured graph bakes in the arena, the freq table and the workspace pointer and the plan's launch list:
-        # key on all of them (plan.generation changes with every set_option); the workspace is private to the state
+        # key on all of them (plan.generation changes with every set_option); the workspace is private to the state.
+        # item_streams: one torch generator per image of the batch (`item_seeds` of p_sample_loop) -- the generators are
+        # registered with the captured graph, so they belong to the state and are re-seeded per loop
         un = self.denoise_fn
         key = (tuple(shape), None if cond_shape is None else tuple(cond_shape), str(dev), self.num_timesteps,
-               un.arena.data_ptr(), un.freq.data_ptr(), un.plan.generation)
+               un.arena.data_ptr(), un.freq.data_ptr(), un.plan.generation, bool(item_streams))
         st = self._loop_cache.get(key)
         if st is None:
             st = dict(img=torch.empty(shape, device=dev), z=torch.empty(shape, device=dev),
                       eps=torch.empty(shape, device=dev),
                       cond=None if cond_shape is None else torch.empty(cond_shape, device=dev),
-                      step=torch.zeros(2, dtype=torch.int32, device=dev), graph=None, ws=E.Workspace())      # [scratch, t]
+                      step=torch.zeros(2, dtype=torch.int32, device=dev), graph=None, ws=E.Workspace(),      # [scratch, t]
+                      gens=[torch.Generator(device=dev) for _ in range(shape[0])] if item_streams else None)
             self._loop_cache = {key: st}       # keep one shape alive at a time
         return st
+
+    @staticmethod
+    def _draw(t, gens):
+        """t ~ N(0, 1): one draw for the batch from the default generator (the reference's torch.randn_like), or image i's slab
+        from ITS generator -- a slab is contiguous and has the numel of a batch-1 tensor, so torch's Philox kernel gives image i
+        the values a batch-1 chain with the same generator state gets, whatever batch the image rides in."""
+        if gens is None:
+            t.normal_()
+        else:
+            for i, g in enumerate(gens):
+                t[i].normal_(generator=g)
 
     def _one_step(self, st, draw_noise=True):
         """One iteration of the loop: z ~ N(0, 1) (torch's graph-safe Philox), then sr3_reverse_step -- UNet forward with the p_sample
         update and the counter decrement inside the output conv's kernel (round 6; before: three calls, two more graph nodes).
         st['eps'] keeps the step's eps for the parity checks that read it."""
         if draw_noise:
-            st['z'].normal_()
+            self._draw(st['z'], st['gens'])
         tables = (self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
                   self.posterior_mean_coef2, self._sigma)
         self.denoise_fn.reverse_step(st['img'], st['z'], tables, st['step'], cond=st['cond'], level_table=self._level_table,
@@ -199,6 +213,8 @@ class EngineDiffusion(nn.Module):
         # one eager step on scratch data first (lazy kernel attributes, allocator warm-up), with the
         # RNG state restored afterwards so a seed reproduces the reference's draw sequence
         rng = torch.cuda.get_rng_state(dev)
+        gens = st['gens'] or []
+        gstate = [g.get_state() for g in gens]
         keep_img = st['img'].clone()
         keep_step = st['step'].clone()
         side = torch.cuda.Stream(dev)
@@ -210,16 +226,23 @@ class EngineDiffusion(nn.Module):
         st['img'].copy_(keep_img)
         st['step'].copy_(keep_step)
         torch.cuda.set_rng_state(rng, dev)
+        for gen, gs in zip(gens, gstate):
+            gen.set_state(gs)
         g = torch.cuda.CUDAGraph()
+        for gen in gens:                       # (the default generator registers itself at capture_begin; these do not)
+            g.register_generator_state(gen)
         with torch.cuda.graph(g):
             self._one_step(st)
         # capture does not execute; state is untouched
         st['graph'] = g
 
     @torch.no_grad()
-    def p_sample_loop(self, x_in, continous=False, *, x_T=None, noise_seq=None):
-        """sr3 diffusion.py:176-200 / ddpm :200-230.  Extensions (used by the parity tests): `x_T`
-        injects the initial draw, `noise_seq[i]` the noise consumed at step i."""
+    def p_sample_loop(self, x_in, continous=False, *, x_T=None, noise_seq=None, item_seeds=None):
+        """sr3 diffusion.py:176-200 / ddpm :200-230.  Extensions: `x_T` injects the initial draw, `noise_seq[i]` the noise
+        consumed at step i (the parity tests); `item_seeds` (one int per image of the batch) gives every image its own noise
+        stream -- x_T and every step's z of image i come from a generator seeded with item_seeds[i], so the image's chain does
+        not depend on which batch it rides in (sr3_hip.dist.ValWave batches the validation items the reference's infer.py /
+        sr.py feed one by one, infer.py:67-71)."""
         dev = self.betas.device
         if dev.type != 'cuda':
             raise L.Sr3Error('p_sample_loop needs the model on a GPU (set gpu_ids); there is no CPU fallback')
@@ -231,10 +254,21 @@ class EngineDiffusion(nn.Module):
         else:
             cond = x_in.to(dev, torch.float32).contiguous()
             shape = tuple(cond.shape)
-        st = self._loop_state(shape, None if cond is None else shape, dev)
+        if item_seeds is not None:
+            item_seeds = [int(v) for v in item_seeds]
+            if len(item_seeds) != shape[0]:
+                raise L.Sr3Error('p_sample_loop: %d item_seeds for a batch of %d' % (len(item_seeds), shape[0]))
+            if noise_seq is not None:
+                raise L.Sr3Error('p_sample_loop: item_seeds and noise_seq exclude each other')
+        st = self._loop_state(shape, None if cond is None else shape, dev, item_streams=item_seeds is not None)
         self.denoise_fn.ensure_derived()       # a replayed graph does not pass through EngineUNet.forward
+        if item_seeds is not None:
+            for g, v in zip(st['gens'], item_seeds):
+                g.manual_seed(v)
         if x_T is not None:
             st['img'].copy_(x_T)
+        elif item_seeds is not None:
+            self._draw(st['img'], st['gens'])
         else:
             st['img'].copy_(torch.randn(shape, device=dev))
         if cond is not None:
@@ -275,12 +309,12 @@ class EngineDiffusion(nn.Module):
         return ret if continous else ret[-1]
 
     @torch.no_grad()
-    def sample(self, batch_size=1, continous=False):
-        return self.p_sample_loop((batch_size, self.channels, self.image_size, self.image_size), continous)
+    def sample(self, batch_size=1, continous=False, *, item_seeds=None):
+        return self.p_sample_loop((batch_size, self.channels, self.image_size, self.image_size), continous, item_seeds=item_seeds)
 
     @torch.no_grad()
-    def super_resolution(self, x_in, continous=False):
-        return self.p_sample_loop(x_in, continous)
+    def super_resolution(self, x_in, continous=False, *, item_seeds=None):
+        return self.p_sample_loop(x_in, continous, item_seeds=item_seeds)
 
     # ---- forward process / loss --------------------------------------------------------------------
     def _q_sample_coef(self, x_start, ca, cb, noise):

@@ -325,17 +325,53 @@ def val_chain_batch():
     return max(1, int(v)) if v not in (None, '') else 16
 
 
+def val_item_streams():
+    """Per-item noise streams of the batched validation chains (default on; SR3_VAL_ITEM_STREAMS=0: one draw per batch from the
+    default torch generator).  Item k of the validation sequence (its j-th image, if a loader batch holds several) draws x_T and
+    every step's z from its own generator, seeded by `val_item_seed(k, j)`: the image it gets does not depend on SR3_VAL_CHAIN_BATCH,
+    on the number of ranks or on which items share its chain -- up to the engine's rounding (kernels differ with the batch size),
+    a batched infer.py run reproduces the one-chain-per-image run the reference makes (infer.py:67-71)."""
+    return os.environ.get('SR3_VAL_ITEM_STREAMS', '1') not in ('0', '')
+
+
+_val_base = [None]
+
+
+def val_base_seed():
+    """Base of the per-item seeds: SR3_VAL_SEED, else the default generator's seed (`torch.manual_seed(s)` in the calling script
+    fixes it; unseeded it is torch's own random seed) -- rank 0's value on every rank."""
+    if _val_base[0] is None:
+        v = os.environ.get('SR3_VAL_SEED')
+        base = int(v) if v not in (None, '') else int(torch.initial_seed())
+        _val_base[0] = broadcast_int(base & 0x7FFFFFFFFFFFFFFF, 0) if dp_active() else base & 0x7FFFFFFFFFFFFFFF
+    return _val_base[0]
+
+
+def val_item_seed(item, image=0, base=None):
+    """Seed of image `image` of validation item `item`: a 63-bit mix of (base, item, image) -- Philox keys need not be far apart,
+    but neighbouring runs (base, base + 1) must not share streams item for item."""
+    x = ((val_base_seed() if base is None else int(base)) + 0x9E3779B97F4A7C15 * (int(item) + 1) + 0xC2B2AE3D27D4EB4F * int(image)) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 31
+    x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 29
+    return x & 0x7FFFFFFFFFFFFFFF
+
+
 class ValWave(object):
     """Up to `world * chain` consecutive validation batches.  Every rank iterates ALL of them in order (so the caller's idx,
     file names and PSNR average are those of a single process -- sr.py:112-141, infer.py:64-90), but the reverse chains run
     once, when the first item of the wave is tested: the items are dealt to the ranks in contiguous runs, a rank runs its items
     of equal shape as ONE chain batch (round 6), the finished images are all-gathered and `DDPM.test` hands item k's to the
     caller when it gets there.  Rides in the batch dict under '_dp_wave'.  With one process the same object batches consecutive
-    items into one chain.  The noise of a batched chain is one draw for the whole batch from the torch RNG: each image is a
-    sample of the same distribution as its batch-1 chain's, not the same realisation (the reference does not seed)."""
+    items into one chain.  Noise: every image draws from its own stream, seeded from its position in the validation sequence
+    (`val_item_streams`, default on) -- the image does not depend on the batch it rides in; with SR3_VAL_ITEM_STREAMS=0 a batched
+    chain takes one draw per batch from the torch RNG (each image a sample of the same distribution as its batch-1 chain's, not the
+    same realisation; the reference does not seed)."""
 
-    def __init__(self, conds):
+    def __init__(self, conds, first_item=0, streams=None):
         self.conds = conds            # list of (B, 3, H, W) conditioning tensors ('SR' entries), one per item
+        self.first_item = int(first_item)        # index of conds[0] in the validation sequence (per-item noise streams)
+        self.streams = val_item_streams() if streams is None else bool(streams)
         self.results = None
         self.continous = None
 
@@ -343,19 +379,25 @@ class ValWave(object):
         return self
 
     @staticmethod
-    def _run_items(netG, conds, continous):
+    def _run_items(netG, conds, continous, items=None):
         """The chains of `conds` (a list), equal shapes batched: returns one result per item, in the form
-        `super_resolution(cond, continous)` has for that item alone."""
+        `super_resolution(cond, continous)` has for that item alone.  `items`: the items' indices in the validation sequence
+        (per-item noise streams), or None (one draw per batch)."""
         out = [None] * len(conds)
         groups = {}
         for i, c in enumerate(conds):
             groups.setdefault(tuple(c.shape), []).append(i)
+
+        def seeds(idx):
+            if items is None:
+                return {}
+            return dict(item_seeds=[val_item_seed(items[i], j) for i in idx for j in range(conds[i].shape[0])])
         for shape, idx in groups.items():
             if len(idx) == 1:
-                out[idx[0]] = netG.super_resolution(conds[idx[0]], continous)
+                out[idx[0]] = netG.super_resolution(conds[idx[0]], continous, **seeds(idx))
                 continue
             b = [conds[i].shape[0] for i in idx]
-            ret = netG.super_resolution(torch.cat([conds[i] for i in idx], dim=0), True)     # (snapshots * sum(b), C, H, W)
+            ret = netG.super_resolution(torch.cat([conds[i] for i in idx], dim=0), True, **seeds(idx))     # (snapshots * sum(b), C, H, W)
             n = sum(b)
             snaps = ret.view(ret.shape[0] // n, n, *ret.shape[1:])
             lo = 0
@@ -369,14 +411,17 @@ class ValWave(object):
     def run(self, netG, continous):
         rank, world, _ = dp_info()
         n = len(self.conds)
+        items = [self.first_item + i for i in range(n)] if self.streams else None
+        if items:
+            val_base_seed()        # (a broadcast the first time: every rank takes part, also one without items in a ragged wave)
         if not dp_active():
-            self.results = self._run_items(netG, self.conds, continous)
+            self.results = self._run_items(netG, self.conds, continous, items)
             self.continous = continous
             return
         import torch.distributed as tdist
         per = -(-n // world)                       # contiguous runs: rank r owns items [r * per, (r + 1) * per)
         mine = list(range(rank * per, min((rank + 1) * per, n)))
-        own = self._run_items(netG, [self.conds[i] for i in mine], continous) if mine else []
+        own = self._run_items(netG, [self.conds[i] for i in mine], continous, [items[i] for i in mine] if items else None) if mine else []
         # items may differ in shape (an inference set with mixed resolutions) and a ragged last wave leaves ranks with fewer
         # items: per slot, shapes are gathered first, payloads padded to the largest
         dev = own[0].device if own else self.conds[0].device

@@ -103,7 +103,7 @@ def main():
     # sr.py:104-141 -- validation inside training
     calls = []
 
-    def fake_super_resolution(x_in, continous=False):
+    def fake_super_resolution(x_in, continous=False, item_seeds=None):
         calls.append(float(x_in.sum()))
         img = x_in * 0.5 + rank            # tagged with the rank that produced it
         return torch.cat([x_in, img], 0) if continous else img[-1]

@@ -220,17 +220,20 @@ def _valwave_worker(rank, world, port, shapes, ret):
 
     class Net(object):                  # stands in for the reverse loop: result depends on the item and on `continous`
         calls = []
+        seeds = []
 
-        def super_resolution(self, cond, continous):
+        def super_resolution(self, cond, continous, item_seeds=None):
             Net.calls.append(tuple(cond.shape))
+            Net.seeds.append(None if item_seeds is None else list(item_seeds))
             img = cond * 3 + 1
             return torch.cat([cond, img], 0) if continous else img[-1]
     conds = [torch.arange(1 * 3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k for k, (h, w) in enumerate(shapes)]
     out = {}
+    torch.manual_seed(77 + rank)        # (the ranks' own default seeds differ: the per-item seeds follow rank 0's)
     for continous in (True, False):
-        wave = D.ValWave(conds)
+        wave = D.ValWave(conds, first_item=10)
         out[continous] = [wave.result(Net(), pos, continous).clone() for pos in range(len(conds))]
-    ret[rank] = (out, Net.calls)
+    ret[rank] = (out, Net.calls, Net.seeds)
     dist.destroy_process_group()
 
 
@@ -242,10 +245,14 @@ def test_validation_wave_mixed_shapes_and_ragged_wave_two_ranks(shapes):
     port = _free_port()
     ret = mp.Manager().dict()
     mp.spawn(_valwave_worker, args=(world, port, shapes, ret), nprocs=world, join=True)
+    sys.path.insert(0, PKG)
+    from sr3_hip import dist as D
     for r in range(world):
-        out, calls = ret[r]
+        out, calls, seeds = ret[r]
         mine = [(1, 3, h, w) for k, (h, w) in enumerate(shapes) if k == r]
         assert calls == mine * 2, (r, calls)                 # once per `continous` flavour, own item only
+        # per-item noise streams: the item's seed comes from its place in the validation sequence and RANK 0's base, not from the rank it ran on
+        assert seeds == [[D.val_item_seed(10 + k, 0, base=77)] for k in range(len(shapes)) if k == r] * 2, (r, seeds)
         for k, (h, w) in enumerate(shapes):
             cond = torch.arange(3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k
             assert torch.equal(out[True][k], torch.cat([cond, cond * 3 + 1], 0))
@@ -261,18 +268,32 @@ def test_validation_wave_batches_equal_shapes_single_process():
 
     class Net(object):
         calls = []
+        seeds = {}
 
-        def super_resolution(self, cond, continous):                 # two "snapshots": the conditioning, then the result
+        def super_resolution(self, cond, continous, item_seeds=None):                 # two "snapshots": the conditioning, then the result
             Net.calls.append(tuple(cond.shape))
+            Net.seeds[tuple(cond.shape)] = item_seeds
             img = cond * 3 + 1
             return torch.cat([cond, img], 0) if continous else img[-1]
     shapes = [(4, 4), (4, 4), (8, 6), (4, 4), (2, 2)]
     conds = [torch.arange(3 * h * w, dtype=torch.float32).view(1, 3, h, w) + 100 * k for k, (h, w) in enumerate(shapes)]
+    D._val_base[0] = None
+    torch.manual_seed(4242)
     for continous in (True, False):
         Net.calls = []
-        wave = D.ValWave(conds)
+        wave = D.ValWave(conds, first_item=32)
         got = [wave.result(Net(), pos, continous) for pos in range(len(conds))]
         assert sorted(Net.calls) == sorted([(3, 3, 4, 4), (1, 3, 8, 6), (1, 3, 2, 2)]), Net.calls
+        # per-item noise streams (default on): image k of the validation sequence gets seed (base, k) whatever batch it rides in
+        assert Net.seeds[(3, 3, 4, 4)] == [D.val_item_seed(32 + k, 0, base=4242) for k in (0, 1, 3)]
+        assert Net.seeds[(1, 3, 8, 6)] == [D.val_item_seed(34, 0, base=4242)] and Net.seeds[(1, 3, 2, 2)] == [D.val_item_seed(36, 0, base=4242)]
+        assert len({D.val_item_seed(k, j, base=b) for k in range(64) for j in range(2) for b in (4242, 4243)}) == 256
         for k, c in enumerate(conds):
             want = torch.cat([c, c * 3 + 1], 0) if continous else (c * 3 + 1)[-1]
             assert torch.equal(got[k], want), (continous, k)
+    # SR3_VAL_ITEM_STREAMS=0 (or streams=False): one draw per batch from the default generator -- no seeds are passed
+    Net.seeds = {}
+    wave = D.ValWave(conds, streams=False)
+    wave.result(Net(), 0, False)
+    assert all(v is None for v in Net.seeds.values()) and len(Net.seeds) == 3
+    D._val_base[0] = None

@@ -310,6 +310,7 @@ def test_validation_items_batched_into_one_chain_single_process(tmp_path, monkey
     _DL = _tud.DataLoader
     monkeypatch.setattr(_tud, 'DataLoader', lambda *a, **k: _DL(*a, **dict(k, num_workers=0)))
     monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', '4')
+    monkeypatch.setenv('SR3_VAL_ITEM_STREAMS', '0')        # one draw per batch from the default generator (the per-item streams: next test)
     dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
     loader = Data.create_dataloader(Data.create_dataset(dopt, 'val'), dopt, 'val')
     opt = opt_for(NAME, phase='val', gpu=True)
@@ -320,7 +321,7 @@ def test_validation_items_batched_into_one_chain_single_process(tmp_path, monkey
     m.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
     calls = []
     orig = m.netG.super_resolution
-    m.netG.super_resolution = lambda x, continous=False: (calls.append(tuple(x.shape)), orig(x, continous))[1]
+    m.netG.super_resolution = lambda x, continous=False, **kw: (calls.append(tuple(x.shape)), orig(x, continous, **kw))[1]
     outs_c, outs_f, conds = [], [], []
     for continous, outs in ((True, outs_c), (False, outs_f)):
         for idx, val_data in enumerate(loader):
@@ -342,3 +343,69 @@ def test_validation_items_batched_into_one_chain_single_process(tmp_path, monkey
         assert torch.equal(outs_c[k], ref[:, k]), k
         assert torch.equal(outs_f[k], ref[-1, k]), k                   # (same seed: the continous = False pass repeats the chain)
         assert torch.equal(outs_c[k][0], conds[k][0].cpu())            # snapshot 0 is the conditioning image (sr3 diffusion.py:180-187)
+
+
+@pytest.mark.timeout(600)
+def test_batched_validation_chains_draw_per_item_noise_streams(tmp_path, monkeypatch):
+    """Per-item noise streams (sr3_hip.dist.val_item_streams, default on): image k of the validation sequence draws x_T and every
+    step's z from its own generator, so the image `infer.py` gets for it does not depend on the batch it rides in.  Five items run
+    (a) batched 4 + 1 through the captured graph, (b) one chain per image, the way the reference feeds them (infer.py:67-71,
+    data/__init__.py:18), (c) directly through `super_resolution(cond, item_seeds=[seed of k])`: (b) and (c) are the same
+    launches, bit for bit; (a) differs from them only by the engine's rounding between batch sizes (tolerance 1e-4)."""
+    sys.path.insert(0, PKG)
+    from test_oracle_io import _write_triplets
+    import data as Data
+    import model as Model
+    from sr3_hip import dist as D
+    root = str(tmp_path / 'ds')
+    _write_triplets(root, 5, l=4, r=16)
+    import torch.utils.data as _tud
+    _DL = _tud.DataLoader
+    monkeypatch.setattr(_tud, 'DataLoader', lambda *a, **k: _DL(*a, **dict(k, num_workers=0)))
+    monkeypatch.setenv('SR3_VAL_SEED', '1234')
+    monkeypatch.setattr(D, '_val_base', [None])
+    dopt = dict(name='t', mode='LRHR', dataroot=root, datatype='img', l_resolution=4, r_resolution=16, data_len=-1)
+    opt = opt_for(NAME, phase='val', gpu=True)
+    m = Model.create_model(opt)
+    _, sd = load_golden(NAME)
+    m.netG.load_state_dict(sd, strict=True)
+    m.netG.show_progress = False
+    m.set_new_noise_schedule(opt['model']['beta_schedule']['val'], schedule_phase='val')
+    calls = []
+    orig = m.netG.super_resolution
+    m.netG.super_resolution = lambda x, continous=False, **kw: (calls.append((tuple(x.shape), kw.get('item_seeds'))), orig(x, continous, **kw))[1]
+
+    def run(chain, streams):
+        monkeypatch.setenv('SR3_VAL_CHAIN_BATCH', str(chain))
+        if streams is None:
+            monkeypatch.delenv('SR3_VAL_ITEM_STREAMS', raising=False)
+        else:
+            monkeypatch.setenv('SR3_VAL_ITEM_STREAMS', streams)
+        loader = Data.create_dataloader(Data.create_dataset(dopt, 'val'), dopt, 'val')
+        del calls[:]
+        outs, conds = [], []
+        torch.manual_seed(5)             # (the default generator plays no part: SR3_VAL_SEED is the base)
+        for val_data in loader:
+            m.feed_data(val_data)
+            m.test(continous=True)
+            outs.append(m.get_current_visuals(need_LR=False)['SR'].clone())
+            conds.append(val_data['SR'].clone())
+        return outs, conds, list(calls)
+    seeds = [D.val_item_seed(k, 0, base=1234) for k in range(5)]
+    batched, conds, c_b = run(4, None)
+    assert c_b == [((4, 3, 16, 16), seeds[:4]), ((1, 3, 16, 16), seeds[4:])], c_b
+    single, _, c_s = run(1, '1')
+    assert c_s == [((1, 3, 16, 16), [seeds[k]]) for k in range(5)], c_s
+    for k in range(5):
+        direct = orig(conds[k].to(m.device), True, item_seeds=[seeds[k]]).cpu()
+        assert torch.equal(single[k], direct), k
+        assert batched[k].shape == single[k].shape and bool(torch.isfinite(batched[k]).all())
+        d = float((batched[k] - single[k]).abs().max())
+        assert d <= 1e-4, (k, d)
+    # different items draw different streams (same conditioning would still give different images), and a second pass repeats the first
+    assert float((single[0][-1] - single[1][-1]).abs().max()) > 1e-3
+    again, _, _ = run(4, None)
+    assert all(torch.equal(a, b) for a, b in zip(again, batched))
+    # without the streams a batched chain draws per batch: no seeds are passed
+    _, _, c_0 = run(4, '0')
+    assert c_0 == [((4, 3, 16, 16), None), ((1, 3, 16, 16), None)], c_0
