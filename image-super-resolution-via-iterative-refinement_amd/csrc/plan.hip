@@ -452,7 +452,7 @@ struct Builder {
     }
     if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->gemm2 && P->tile_cfg == 0 && P->gemm_tile == 0 && P->wsplit_of.count(w)) {
       // plan option gemm2: 1x1 stride-1 convs -- and Downsample's 3x3 stride-2 ones -- the plain GEMM kernel fits (gemm1x1.hip)
-      if (gemm1x1_fits(c, 2)) {
+      if (gemm1x1_fits(c, 2) && (ksize == 1 || P->gemm_s2)) {
         o.tile_cfg = 22; o.ksplit = P->ksplit;
         conv_pick(c, o.tile_cfg, o.ksplit);
         o.has_wsplit = true; o.wsplit_off = P->wsplit_of[w];
@@ -677,7 +677,7 @@ void layout_derived(sr3_plan* P) {
   if (P->gemm_split && (P->gemm_wpre || P->gemm2)) {
     auto regw = [&](size_t w, int Cout, int taps, int Cin) {
       if (Cin & 3) return;
-      if (!P->gemm_wpre && ((taps != 1 && taps != 9) || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take (1x1; Downsample's 3x3 stride 2)
+      if (!P->gemm_wpre && ((taps != 1 && !(taps == 9 && P->gemm_s2)) || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take (1x1; Downsample's 3x3 stride 2)
       P->wsplits.push_back({w, Cout, taps, Cin, dcur});
       P->wsplit_of[w] = dcur;
       dcur += igemm_wsplit_floats(Cout, taps, Cin);
@@ -1106,6 +1106,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "gemm_split")) slot = &plan->gemm_split;
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm2")) slot = &plan->gemm2;
+  else if (!strcmp(key, "gemm_s2")) slot = &plan->gemm_s2;
   else if (!strcmp(key, "fold_fuse")) slot = &plan->fold_fuse;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino2")) slot = &plan->wino2;
@@ -1123,7 +1124,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
-  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre || slot == &plan->gemm2) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
+  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre || slot == &plan->gemm2 || slot == &plan->gemm_s2) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }
@@ -1439,9 +1440,11 @@ size_t sr3_conv_scratch_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksiz
   }
   size_t extra = 0;
   if (tile_cfg >= 14 && tile_cfg <= 17) { c.igemm_split = 1; tile_cfg -= 13; }
-  if (tile_cfg == 22) {      // the 1x1 GEMM kernel: stride 1, pre-split weights behind the slabs
-    c.igemm_split = 1; c.Hs = Ho; c.Ws = Wo; c.stride = 1;
-    return conv_splitk_bytes(c, tile_cfg, ksplit) + igemm_wsplit_floats(Cout, 1, Cin) * sizeof(float);
+  if (tile_cfg == 22) {      // the GEMM kernel: 1x1 stride 1, or 3x3 stride 2 (ksize 3); pre-split weights behind the slabs
+    c.igemm_split = 1;
+    if (ksize == 3) { c.Hs = 2 * Ho; c.Ws = 2 * Wo; c.stride = 2; }
+    else { c.Hs = Ho; c.Ws = Wo; c.stride = 1; }
+    return conv_splitk_bytes(c, tile_cfg, ksplit) + igemm_wsplit_floats(Cout, ksize * ksize, Cin) * sizeof(float);
   }
   if (tile_cfg >= 18 && tile_cfg <= 21) {      // + the pre-split weights behind the slabs
     c.igemm_split = 1; tile_cfg -= 17;

@@ -127,6 +127,7 @@ struct sr3_plan {
   int fold_fuse = 1;         // the GroupNorm fold of a consumer done by the kernel that completes its (last) source where that is a split-K
                              // reduce or a stand-alone statistics pass (k_rows_fold; round 6): 32 of the 61 fold launches of the C2 forward
   int gemm2 = 1;             // 1x1 stride-1 convs (res_conv, the attention projections) on the plain GEMM kernel of gemm1x1.hip where it fits
+  int gemm_s2 = 1;           // ... and Downsample's 3x3 stride-2 convs on that kernel's stride-2 form (needs gemm2; Cout % 128 == 0)
                              // (Cout % 128 == 0, channels % 32 == 0, rows % 64 == 0): pre-split weights in fragment order read straight from
                              // global memory, A rows split once per 128 output channels, staging arithmetic hand-placed between the MFMAs
                              // (round 6; 27 of the 33 launches of the C2 forward: 1.09 -> 0.80 ms, profiles/r06_gemm1x1.txt).  0: the im2col kernel

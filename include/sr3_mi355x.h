@@ -95,7 +95,7 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
+ * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_s2", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
  * "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
@@ -120,6 +120,10 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   arithmetic (gemm1x1.hip; reported as tile 22): 64 x 128 tile, weights pre-split in MFMA fragment order in the derived buffer
  *   (6 bytes per weight: sr3_plan_derived_bytes grows; re-bind after toggling) and read straight from global memory, the A rows
  *   split once per 128 output channels; a training plan's 1x1 data gradients use it too.  0: the im2col kernel (tiles 14-17).
+ * gemm_s2 (default 1, round 6; needs gemm2): Downsample's 3x3 stride-2 pad-1 convolutions with Cout % 128 == 0 (one source, no
+ *   activation, even maps) run on the same kernel's stride-2 form (also reported as tile 22): the GEMM's k-steps walk (32-channel
+ *   chunk, tap), the A row of a tap is the NHWC row of the shifted input pixel, padding rows are zeroed where they are staged;
+ *   54 bytes per weight in the derived buffer.  0: the im2col kernel (tile 16).
  * fold_fuse (default 1, round 6): the GroupNorm fold of a consumer is done by the kernel that completes its last source where that
  *   is a split-K reduce or a stand-alone statistics pass (one workgroup per (image, consumer group), no atomics): those fold
  *   launches leave the launch list (sr3_plan_num_ops shrinks), the conv outputs are bit-identical, the folded (scale, shift) pairs
@@ -284,9 +288,10 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * instantiation with both operands split while they are staged (what plan option gemm_split selects: what a plan runs), 18-21 =
  * the same with the weights pre-split into bf16 planes in MFMA fragment order and read straight from global memory (plan option
  * gemm_wpre, default off: a plan keeps the planes in its derived buffer; this entry point derives them into `scratch`; results
- * are bit-identical to 14-17); 22 = the plain GEMM kernel of gemm1x1.hip (what plan option gemm2 -- default on -- selects: 1x1
- * stride 1, no upsampling, Cout % 128 == 0, C0 and C1 % 32 == 0, B * H * W % 64 == 0, H * W % 32 == 0, act 0 | 1; anything else
- * is refused with "does not fit"; same pre-split weights as 18-21, derived into `scratch`).
+ * are bit-identical to 14-17); 22 = the plain GEMM kernel of gemm1x1.hip (what plan options gemm2 / gemm_s2 -- default on -- select: 1x1
+ * stride 1, or 3x3 stride 2 with one source, act 0 and an even map; no upsampling, Cout % 128 == 0, C0 and C1 % 32 == 0,
+ * B * Ho * Wo % 64 == 0, Ho * Wo % 32 == 0, act 0 | 1; anything else is refused with "does not fit"; same pre-split weights as
+ * 18-21, derived into `scratch`).
  * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-22), sized by
  * sr3_conv_scratch_bytes. */
 int sr3_conv_f32(const float* src0, int C0, const float* src1, int C1, int B, int Hs, int Ws, int ups,

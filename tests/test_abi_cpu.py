@@ -172,18 +172,26 @@ def test_plan_launch_list_no_gpu():
     assert wops[1]['kind'] == 20 and wops[1]['fused_output_stats'] and wops[2]['kind'] == 40
     # plan option gemm2 (default 1, round 6): the 1x1 stride-1 convs with Cout % 128 == 0 run the plain GEMM kernel of gemm1x1.hip
     # (tile 22; rows % 64 == 0 and channels % 32 == 0 hold for every layer of this network), reading their weights pre-split in MFMA
-    # fragment order from the derived buffer (6 bytes per weight); the Cout = 64 res_convs and the Downsample convs keep the im2col kernel
+    # fragment order from the derived buffer (6 bytes per weight); the Cout = 64 res_convs keep the im2col kernel.  Last session of round 6:
+    # Downsample's 3x3 stride-2 convs with Cout % 128 == 0 run the same kernel's stride-2 form (9 k-steps per 32-channel chunk)
     dconvs = [o for o in wops if o['kind'] == 50]
     for o in dconvs:
-        assert (o['tile_cfg'] == 22) == (o['ksize'] == 1 and o['stride'] == 1 and o['cout'] % 128 == 0), o
+        s2 = o['ksize'] == 3 and o['stride'] == 2
+        assert (o['tile_cfg'] == 22) == (((o['ksize'] == 1 and o['stride'] == 1) or s2) and o['cout'] % 128 == 0), o
         if o['tile_cfg'] == 22:        # split-K only below 128 workgroups; tile rows 64, or 32 where 64-row tiles leave slots empty (gemm1x1_rows)
             M = 16 * o['h_out'] * o['w_out']
-            rows = 64 if (M // 64) * (o['cout'] // 128) >= 384 else (32 if (M <= 1024 or o['cin'] <= 512) else 64)
-            assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // 128) < 128), o
-    assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 27
+            rows = 64 if (M // 64) * (o['cout'] // 128) >= 384 else (32 if (s2 or M <= 1024 or o['cin'] <= 512) else 64)
+            # (the stride-2 form: long K on small maps -- it splits whenever its tiles do not fill the 512 workgroup slots)
+            assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // 128) < (512 if s2 else 128)), o
+    assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 30
+    assert [(o['cin'], o['h_out'], o['ksplit']) for o in dconvs if o['tile_cfg'] == 22 and o['ksize'] == 3] == [(128, 32, 1), (256, 16, 2), (512, 8, 4)]
+    p.set_option('gemm_s2', 0)         # plan option gemm_s2 = 0: the three Downsample convs back on the im2col split tile, nothing else moves
+    sops = [o for o in p.op_list(16) if o['kind'] == 50]
+    assert [(a['tile_cfg'], b['tile_cfg']) for a, b in zip(dconvs, sops) if a['tile_cfg'] != b['tile_cfg']] == [(22, 16)] * 3
+    p.set_option('gemm_s2', 1)
     nbytes_gemm2 = int(p.lib.sr3_plan_derived_bytes(p.handle))
     p.set_option('gemm2', 0)           # the rest of this test walks the im2col options with gemm2 off
-    assert nbytes_gemm2 - int(p.lib.sr3_plan_derived_bytes(p.handle)) == 6 * sum(o['cout'] * o['cin'] for o in dconvs if o['tile_cfg'] == 22)
+    assert nbytes_gemm2 - int(p.lib.sr3_plan_derived_bytes(p.handle)) == 6 * sum(o['cout'] * o['cin'] * o['ksize'] ** 2 for o in dconvs if o['tile_cfg'] == 22)
     wops0 = p.op_list(16)
     assert len(wops0) == p.num_ops(16) == 168
     for a, b in zip([o for o in wops if o['kind'] == 50], [o for o in wops0 if o['kind'] == 50]):

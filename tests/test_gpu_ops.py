@@ -350,7 +350,13 @@ GEMM_SPLIT_CASES = [
     ('qkv_64x64_c1024', 1, 1024, 0, 32, 32, 3072, 1, 1, 0, 1, False, False, False),
     ('down_128', 1, 64, 0, 128, 128, 64, 3, 2, 0, 0, False, False, True),
     ('down_16', 2, 512, 0, 16, 16, 512, 3, 2, 0, 0, False, False, True),
+    ('down_rect_32x64', 2, 128, 0, 32, 64, 256, 3, 2, 0, 0, False, False, True),
 ]
+
+
+def _gemm1x1_fits(k, stride, Cout, C1=0, act=0):
+    """What gemm1x1.hip takes (tile 22): 1x1 stride 1, or Downsample's bare 3x3 stride 2 (one source, no activation); Cout % 128 == 0."""
+    return Cout % 128 == 0 and ((k == 1 and stride == 1) or (k == 3 and stride == 2 and C1 == 0 and act == 0))
 
 
 @pytest.mark.parametrize('tile,ksplit', [(14, 1), (16, 1), (15, 2), (18, 1), (19, 1), (20, 1), (21, 1), (19, 2), (20, 3), (22, 1), (22, 2), (22, 0), (0, 0)])
@@ -364,8 +370,8 @@ def test_gemm_split_error_not_above_fp32_mfma(case, tile, ksplit):
     if tile in (14, 17, 18, 21) and case[6] <= 64:
         pytest.skip('128-wide tiles are not used for Cout <= 64')
     src0, src1, w, kw = _make_case(case, seed=11)
-    if tile == 22 and (case[7] != 1 or case[8] != 1 or case[6] % 128):
-        # tile 22 = the plain GEMM kernel of gemm1x1.hip (plan option gemm2): 1x1 stride 1, Cout % 128 == 0 only -- asserted, not skipped
+    if tile == 22 and not _gemm1x1_fits(case[7], case[8], case[6], case[3], case[10]):
+        # tile 22 = the plain GEMM kernel of gemm1x1.hip (plan option gemm2): 1x1 stride 1 or 3x3 stride 2, Cout % 128 == 0 only -- asserted, not skipped
         with pytest.raises(L.Sr3Error, match='does not fit'):
             G.conv_call(src0, src1, w, tile_cfg=22, ksplit=ksplit, **kw)
         return
@@ -433,8 +439,8 @@ def test_gemm_split_stress_absolute_bound(case, ksplit, tile):
         if act == 2:
             a = a * torch.sigmoid(a)
     src0, src1 = (x[:, :C0].contiguous(), x[:, C0:].contiguous()) if C1 else (x, None)
-    if tile == 22 and (k != 1 or stride != 1 or Cout % 128):
-        with pytest.raises(L.Sr3Error, match='does not fit'):        # the plain GEMM kernel: 1x1 stride 1 only
+    if tile == 22 and not _gemm1x1_fits(k, stride, Cout, C1, act):
+        with pytest.raises(L.Sr3Error, match='does not fit'):        # the plain GEMM kernel: 1x1 stride 1 / bare 3x3 stride 2 only
             G.conv_call(src0, src1, w, tile_cfg=22, ksplit=ksplit, **kw)
         return
     got, _ = G.conv_call(src0, src1, w, tile_cfg=tile, ksplit=ksplit, **kw)
