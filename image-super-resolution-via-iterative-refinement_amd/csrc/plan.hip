@@ -526,6 +526,19 @@ struct Builder {
     flops += 2.0 * B * Ho * Wo * (double)Cout * (double)(C0 + C1) * ksize * ksize;
     return out;
   }
+  // fork_side: is res_conv its own launch in this block (block2's conv has no fused 1x1 segment)?  Same rule as can_fuse_x2, asked before h1 exists
+  bool wino_fits_block2(int x0, const ResLayer& R) {
+    if (!P->fuse_res) return true;
+    ConvParams c;
+    memset(&c, 0, sizeof(c));
+    c.C0 = R.cout; c.B = B; c.Hs = T[x0].H; c.Ws = T[x0].W; c.stride = 1; c.ksize = 3;
+    c.Ho = T[x0].H; c.Wo = T[x0].W; c.Cout = R.cout;
+    c.act = 2;
+    if (wino_ok(c, R.c2_w, false, train)) return true;
+    int cfg = P->tile_cfg, ks = P->ksplit;
+    conv_pick(c, cfg, ks);
+    return !(cfg >= 5 && ks == 1);
+  }
   // can block2's conv run on the halo kernel (which can take res_conv as a second K-segment)?
   bool can_fuse_x2(int h1, int Cout, size_t w) {
     if (!P->fuse_res) return false;
@@ -543,11 +556,25 @@ struct Builder {
     // 1024-channel res_conv at 8x8: measured 43 TF): small-M layers keep res_conv as its own 1x1 GEMM
     return cfg >= 5 && ks == 1;
   }
+  int n_side = 0;          // plan option fork_side: ops handed to the side stream so far (Op::side_id)
   int res_block(int x0, int x1, const ResLayer& R) {
     fold(x0, x1, R.gn1_w, R.gn1_b);
+    // plan option fork_side (inference): res_conv reads only the block input, so it is emitted HERE -- behind the fold, in front of block1's
+    // conv -- and launched on the side stream; block2's conv, which adds it as its residual, waits for it.  Only unsplit: a split-K res_conv
+    // would share the slab region with block1's conv.  (The fold stays where fold_fuse looks for it: behind the op that completes x.)
+    int r_side = -1, r_id = -1;
+    if (R.has_rc && P->fork_side && !train && wino_fits_block2(x0, R)) {
+      r_side = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
+      if (ops.back().kind == OP_CONV && ops.back().ksplit == 1) { r_id = n_side++; ops.back().side_id = r_id; }
+    }
     const int h1 = conv(x0, x1, R.cout, 3, 1, 0, 2, R.c1_w, true, R.c1_b, R.film_off, -1, -1, true);
     fold(h1, -1, R.gn2_w, R.gn2_b);
     int out;
+    if (r_side >= 0) {
+      out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, r_side, -1, true, -1, -1, 0, 0, R.film_off);
+      if (r_id >= 0) ops[last_conv_op].wait_id = r_id;
+      drop(r_side);
+    } else
     if (R.has_rc && can_fuse_x2(h1, R.cout, R.c2_w)) {
       out = conv(h1, -1, R.cout, 3, 1, 0, 2, R.c2_w, true, R.c2_b, -1, -1, -1, true, x0, x1, R.rc_w, R.rc_b, R.film_off);
     } else if (R.has_rc) {
@@ -707,6 +734,15 @@ static int build_forward(sr3_plan* P, int B, int cond_channels) {
   Builder bld(P, B);
   const int inner = d.inner_channel;
   walk_forward(P, bld, cond_channels);
+  if (P->fork_side && !P->ops.empty() && P->ops[0].kind == OP_EMBED) {
+    // ... and the embedding MLP + FiLM projections (first op, reads only the noise level): beside the input conv, joined by the first conv that
+    // adds a FiLM row
+    for (Op& o : P->ops)
+      if (o.kind == OP_CONV && o.has_film) {
+        if (o.wait_id < 0) { o.wait_id = bld.n_side; P->ops[0].side_id = bld.n_side++; }
+        break;
+      }
+  }
   // ---- fixed regions after the activation arena (high-water mark) ----
   size_t off = (bld.act.high + 255) & ~(size_t)255;
   P->stats_off = off; P->stats_bytes = bld.stats_cursor; off += (bld.stats_cursor + 255) & ~(size_t)255;
@@ -749,10 +785,29 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
   const sr3_unet_desc& d = P->d;
   size_t op_index = 0;
   float* film = reinterpret_cast<float*>(ws + R.film_off);
+  // plan option fork_side: ops marked side_id run on the plan's side stream between a fork event (recorded on the caller's stream where the
+  // op sits in the list) and a join event their consumer (wait_id) waits for; under per-op timing (ev) everything stays on one stream
+  const bool forking = !ev && R.ops == &P->ops;
+  hipStream_t const main_st = st;
   for (const Op& o : *R.ops) {
     int rc = SR3_OK;
+    st = main_st;
     if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
     ++op_index;
+    if (forking && o.wait_id >= 0 && o.wait_id < (int)P->join_ev.size())
+      SR3_HIP(hipStreamWaitEvent(main_st, P->join_ev[o.wait_id], 0));
+    if (forking && o.side_id >= 0) {
+      if (!P->side_stream) SR3_HIP(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking));
+      while ((int)P->fork_ev.size() <= o.side_id) {
+        hipEvent_t a, b;
+        SR3_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        SR3_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        P->fork_ev.push_back(a); P->join_ev.push_back(b);
+      }
+      SR3_HIP(hipEventRecord(P->fork_ev[o.side_id], main_st));
+      SR3_HIP(hipStreamWaitEvent(P->side_stream, P->fork_ev[o.side_id], 0));
+      st = P->side_stream;
+    }
     switch (o.kind) {
       case OP_RESERVED:
         break;
@@ -849,7 +904,9 @@ int run_forward(sr3_plan* P, const Regions& R, const float* x, const float* cond
         break;
     }
     if (rc) return rc;
+    if (forking && o.side_id >= 0) SR3_HIP(hipEventRecord(P->join_ev[o.side_id], st));
   }
+  st = main_st;
   if (ev) SR3_HIP(hipEventRecord(ev[op_index], st));
   return SR3_OK;
 }
@@ -1083,6 +1140,16 @@ int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out) {
   }
   return SR3_OK;
 }
+int sr3_plan_op_side(sr3_plan* plan, int batch, int index, int* side_id, int* wait_id) {
+  if (!plan) { set_error("null argument"); return SR3_E_BADARG; }
+  const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
+  const int rc = build_forward(plan, batch, cond);
+  if (rc) return rc;
+  if (index < 0 || index >= (int)plan->ops.size()) { set_error("op index out of range"); return SR3_E_BADARG; }
+  if (side_id) *side_id = plan->ops[index].side_id;
+  if (wait_id) *wait_id = plan->ops[index].wait_id;
+  return SR3_OK;
+}
 double sr3_plan_forward_flops(sr3_plan* plan, int batch) {
   if (!plan) return 0;
   const int cond = plan->built_cond >= 0 ? plan->built_cond : 0;
@@ -1107,6 +1174,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "gemm_wpre")) slot = &plan->gemm_wpre;
   else if (!strcmp(key, "gemm2")) slot = &plan->gemm2;
   else if (!strcmp(key, "gemm_s2")) slot = &plan->gemm_s2;
+  else if (!strcmp(key, "fork_side")) slot = &plan->fork_side;
   else if (!strcmp(key, "fold_fuse")) slot = &plan->fold_fuse;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino2")) slot = &plan->wino2;

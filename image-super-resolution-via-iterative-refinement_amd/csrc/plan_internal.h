@@ -62,6 +62,11 @@ struct Op {
   ConvParams cp;                   // OP_CONV geometry (pointers filled at launch)
   int tile_cfg = 0, ksplit = 0;
   size_t wino_off = 0;             // tile_cfg 11: float offset of this conv's transformed filters in the derived buffer
+  // plan option fork_side (inference plans): side_id >= 0 -- this op depends on nothing the ops between it and its consumer write, so it
+  // is launched on the plan's side stream (forked from the caller's stream by an event, joined by event side_id); wait_id >= 0 -- the
+  // caller's stream waits for join event wait_id before this op (the consumer).  Inside a stream capture the pair becomes a parallel
+  // branch of the graph.
+  int side_id = -1, wait_id = -1;
   bool has_wsplit = false;         // im2col SPLIT tile: its weights pre-split into bf16 planes sit in the derived buffer ...
   size_t wsplit_off = 0;           // ... at this float offset (ConvParams::w_split)
 };
@@ -127,10 +132,19 @@ struct sr3_plan {
   int fold_fuse = 1;         // the GroupNorm fold of a consumer done by the kernel that completes its (last) source where that is a split-K
                              // reduce or a stand-alone statistics pass (k_rows_fold; round 6): 32 of the 61 fold launches of the C2 forward
   int gemm2 = 1;             // 1x1 stride-1 convs (res_conv, the attention projections) on the plain GEMM kernel of gemm1x1.hip where it fits
-  int gemm_s2 = 1;           // ... and Downsample's 3x3 stride-2 convs on that kernel's stride-2 form (needs gemm2; Cout % 128 == 0)
                              // (Cout % 128 == 0, channels % 32 == 0, rows % 64 == 0): pre-split weights in fragment order read straight from
                              // global memory, A rows split once per 128 output channels, staging arithmetic hand-placed between the MFMAs
                              // (round 6; 27 of the 33 launches of the C2 forward: 1.09 -> 0.80 ms, profiles/r06_gemm1x1.txt).  0: the im2col kernel
+  int gemm_s2 = 1;           // ... and Downsample's 3x3 stride-2 convs on that kernel's stride-2 form (needs gemm2; Cout % 128 == 0; last session of
+                             // round 6: the three launches of the C2 forward 171 -> 118 us)
+  int fork_side = 0;         // res_conv (and the embedding MLP) on a side stream beside block1's conv: see Op::side_id; A/B knob
+  hipStream_t side_stream = nullptr;          // fork_side: created at the first forked forward, on the device current then
+  std::vector<hipEvent_t> fork_ev, join_ev;   // one pair per forked op of the compiled forward
+  ~sr3_plan() {
+    for (hipEvent_t e : fork_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : join_ev) (void)hipEventDestroy(e);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+  }
   // derived weights: U = G g G^T of every 3x3 stride-1 conv, fragment-major (caller-owned buffer, bound by pointer)
   struct Derived { size_t w; int Cout, Cin; size_t off; };
   std::vector<Derived> derived;

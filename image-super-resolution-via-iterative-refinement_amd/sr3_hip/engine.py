@@ -91,10 +91,15 @@ class Plan(object):
     def op_list(self, batch):
         """The ordered launch list of one forward at this batch size (host-only inspection)."""
         info = L.OpInfo()
+        side, wait = C.c_int(), C.c_int()
         out = []
         for i in range(self.num_ops(batch)):
             L.check(self.lib.sr3_plan_op_info(self.handle, int(batch), i, C.byref(info)))
-            out.append({k: getattr(info, k) for k, _ in L.OpInfo._fields_})
+            o = {k: getattr(info, k) for k, _ in L.OpInfo._fields_}
+            L.check(self.lib.sr3_plan_op_side(self.handle, int(batch), i, C.byref(side), C.byref(wait)))
+            if side.value >= 0 or wait.value >= 0:      # plan option fork_side: ops on the side stream / the consumers that join them
+                o['side_id'], o['wait_id'] = side.value, wait.value
+            out.append(o)
         return out
 
     def taps(self):

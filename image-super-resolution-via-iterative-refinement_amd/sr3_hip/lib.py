@@ -64,6 +64,7 @@ SIGNATURES = {
     'sr3_plan_param_info': (_I, [_P, _I, C.POINTER(ParamInfo)]),
     'sr3_plan_param_floats': (_Z, [_P]),
     'sr3_plan_op_info': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(OpInfo)]),
+    'sr3_plan_op_side': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'sr3_plan_num_ops': (_I, [_P, _I]),
     'sr3_plan_forward_flops': (C.c_double, [_P, _I]),
     'sr3_plan_set_option': (_I, [_P, C.c_char_p, _I]),

@@ -92,10 +92,14 @@ typedef struct sr3_op_info {
   double flops;
 } sr3_op_info;
 int sr3_plan_op_info(sr3_plan* plan, int batch, int index, sr3_op_info* out);
+/* plan option fork_side: *side_id >= 0 -- op `index` is launched on the plan's side stream, forked from the caller's stream by an event
+ * where the op sits in the list; *wait_id >= 0 -- the caller's stream waits for the side op of that id before this op (its consumer).
+ * Both -1 for every op of a plan without the option.  Host-only. */
+int sr3_plan_op_side(sr3_plan* plan, int batch, int index, int* side_id, int* wait_id);
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_s2", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
+ * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_s2", "fork_side", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
  * "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
@@ -124,6 +128,9 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   activation, even maps) run on the same kernel's stride-2 form (also reported as tile 22): the GEMM's k-steps walk (32-channel
  *   chunk, tap), the A row of a tap is the NHWC row of the shifted input pixel, padding rows are zeroed where they are staged;
  *   54 bytes per weight in the derived buffer.  0: the im2col kernel (tile 16).
+ * fork_side (default 0; A/B knob, inference plans): every unsplit res_conv is emitted in front of its block's first conv and launched
+ *   on a side stream the plan owns (fork / join by events: a parallel branch once the forward is captured into a graph), block2's conv
+ *   waits for it; the embedding MLP runs beside the input conv the same way.  Results are bit-identical (same kernels, same operands).
  * fold_fuse (default 1, round 6): the GroupNorm fold of a consumer is done by the kernel that completes its last source where that
  *   is a split-K reduce or a stand-alone statistics pass (one workgroup per (image, consumer group), no atomics): those fold
  *   launches leave the launch list (sr3_plan_num_ops shrinks), the conv outputs are bit-identical, the folded (scale, shift) pairs

@@ -185,6 +185,26 @@ def test_plan_launch_list_no_gpu():
             assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // 128) < (512 if s2 else 128)), o
     assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 30
     assert [(o['cin'], o['h_out'], o['ksplit']) for o in dconvs if o['tile_cfg'] == 22 and o['ksize'] == 3] == [(128, 32, 1), (256, 16, 2), (512, 8, 4)]
+    # plan option fork_side (default 0): every unsplit res_conv is emitted in front of its block's first conv and marked for the side stream,
+    # block2's conv -- which adds it as its residual -- waits for it; the embedding MLP beside the input conv, joined by the first FiLM conv.
+    # Same ops, same flops; nothing is marked in the default plan
+    assert not any('side_id' in o for o in wops)
+    p.set_option('fork_side', 1)
+    kops = p.op_list(16)
+    assert len(kops) == len(wops) and sum(o['flops'] for o in kops) == sum(o['flops'] for o in wops)
+    sides = {o['side_id']: i for i, o in enumerate(kops) if o.get('side_id', -1) >= 0}
+    waits = {o['wait_id']: i for i, o in enumerate(kops) if o.get('wait_id', -1) >= 0}
+    assert sorted(sides) == sorted(waits) == list(range(19))                 # 18 res_convs + the embedding
+    for k, i in sides.items():
+        a, b = kops[i], kops[waits[k]]
+        assert waits[k] > i and b['kind'] == 50 and b['ksize'] == 3
+        if a['kind'] == 10:
+            assert i == 0 and waits[k] == 3                                    # embedding | input conv, fold -> first block's conv joins
+        else:
+            assert a['kind'] == 50 and a['ksize'] == 1 and a['ksplit'] == 1 and a['cout'] == b['cout'] == b['cin'] and a['h_out'] == b['h_out']
+            assert kops[i + 1]['kind'] == 50 and kops[i + 1]['ksize'] == 3 and kops[i + 1]['cin'] == a['cin']      # block1's conv follows: same input
+    p.set_option('fork_side', 0)
+    assert p.op_list(16) == wops
     p.set_option('gemm_s2', 0)         # plan option gemm_s2 = 0: the three Downsample convs back on the im2col split tile, nothing else moves
     sops = [o for o in p.op_list(16) if o['kind'] == 50]
     assert [(a['tile_cfg'], b['tile_cfg']) for a, b in zip(dconvs, sops) if a['tile_cfg'] != b['tile_cfg']] == [(22, 16)] * 3

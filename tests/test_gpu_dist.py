@@ -117,6 +117,8 @@ def _val_main(rank, world, port, root, ret):
                           WORLD_SIZE=str(world), SR3_DP='force')
     import torch.distributed as dist
     os.environ['SR3_VAL_CHAIN_BATCH'] = '1'          # one chain per image, as the reference: this test is about the dealing over ranks
+    os.environ['SR3_VAL_ITEM_STREAMS'] = '0'         # ... with the chains seeded through the default generator, which a plain single process
+                                                     # shares (the per-item streams: test_batched_validation_chains_draw_per_item_noise_streams)
     try:
         import data as Data
         import model as Model

@@ -48,6 +48,35 @@ def test_unet_forward_and_layer_taps(name, fuse):
     G.assert_close(eps.cpu(), torch.from_numpy(g['unet/eps']), what=name + ' eps')
 
 
+@pytest.mark.parametrize('name', ['sr3_tiny', 'ddpm_tiny'])
+def test_fork_side_option_is_bit_identical_eager_and_captured(name):
+    """Plan option fork_side (res_conv and the embedding MLP on the plan's side stream, forked / joined by events): the same kernels on the
+    same operands, so the forward is bit-identical to the serial plan's -- launched eagerly, and as the captured graph of the reverse loop
+    (where the pairs become parallel branches), under the same seed."""
+    m, g, sd = build(name)
+    un = m.netG.denoise_fn
+    d = G.dev()
+    x = torch.from_numpy(g['unet/x']).to(d)
+    t = torch.from_numpy(g['unet/time']).to(d)
+
+    def loop():
+        torch.manual_seed(17)
+        if CONDITIONAL[name]:
+            return m.netG.super_resolution(torch.from_numpy(g['unet/x'][:, :3]).to(d), True).clone()
+        return m.netG.sample(2, True).clone()
+    e0 = un(x, t).clone()
+    l0 = loop()
+    un.plan.set_option('fork_side', 1)
+    ops = un.plan.op_list(x.shape[0])
+    assert sum(1 for o in ops if o.get('side_id', -1) >= 0) >= 2, 'nothing was forked'
+    for _ in range(3):                       # (repeated: a missing join shows as a race, not every time)
+        assert torch.equal(un(x, t), e0)
+    assert m.netG.use_graph
+    l1 = loop()
+    assert torch.equal(l1, l0)
+    assert torch.isfinite(l1).all()
+
+
 @pytest.mark.experiments
 @pytest.mark.parametrize('name', NAMES)
 def test_unet_forward_split_bf16_option(name):
