@@ -527,7 +527,7 @@ void conv_pick(const ConvParams& p, int& tile_cfg, int& ksplit) {
   if (tile_cfg == 22) {
     // 1x1 GEMM kernel (gemm1x1.hip; two workgroups per CU): split K below one round of workgroups, >= 4 k-steps (128 channels) per split
     if (ksplit == 0) {
-      const long tiles = (long)(M / gemm1x1_rows(p)) * (p.Cout / 128);
+      const long tiles = (long)(M / gemm1x1_rows(p)) * (p.Cout / gemm1x1_cols(p));
       int ks = 1;
 #ifndef SR3_G1_SPLIT_BELOW
 #define SR3_G1_SPLIT_BELOW 128

@@ -54,16 +54,24 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // the A row of output pixel (b, oh, ow) for tap (ky, kx) is the NHWC row of input pixel (2 oh + ky - 1, 2 ow + kx - 1): a per-step uniform
 // offset added to the row's base address.  Padding touches only the top row / left column of the map (even H, W): those rows load the
 // centre pixel instead (an address select, no branch) and are zeroed where the staged value is picked up.
-template <int MI, bool ACT, bool S2 = false>
+// WM = 2 (last session of round 6): the 64-column tile for Cout % 128 != 0 (the res_convs of the 128 x 128 level, Downsample 64 -> 64, data
+// gradients towards 64 / 192 channels) -- the four waves sit 2 (M) x 2 (N): a wave owns ONE 32-column block and the MI m blocks of its half of
+// the rows; the workgroup stages MQ = MI * WM m blocks per k-step (the staging arithmetic per MFMA doubles: these layers are bound by their A
+// rows from HBM, not by the matrix pipe).
+template <int MI, bool ACT, bool S2 = false, int WM = 1>
 __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   static_assert(!(ACT && S2), "the stride-2 form has no GroupNorm affine");
-  constexpr int BM = 32 * MI;
+  static_assert(WM == 1 || WM == 2, "waves along M");
+  constexpr int NWN = 4 / WM;                   // waves side by side along N
+  constexpr int MQ = MI * WM;                   // m blocks the workgroup stages per k-step
+  constexpr int BM = 32 * MQ;
   constexpr int FRAG = 64 * 16;                 // bytes of one operand fragment (64 lanes x 8 bf16)
-  constexpr int STAGE = 2 * MI * 3 * FRAG;      // [K = 16 step 2][m block MI][plane 3][FRAG]
+  constexpr int STAGE = 2 * MQ * 3 * FRAG;      // [K = 16 step 2][m block MQ][plane 3][FRAG]
   extern __shared__ f32x4 smem_v[];
   char* smem = reinterpret_cast<char*>(smem_v);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % NWN, wm = wave / NWN;
   const int Cin = p.C0 + p.C1;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   const int it0 = blockIdx.y * per;
   const int it1 = min(total, it0 + per);
   const int nsteps = it1 - it0;
-  const int tiles_n = p.Cout >> 7;
+  const int tiles_n = p.Cout / (32 * NWN);
   // XCD-aware order: consecutive tile ids (n fastest: they share their A rows) run on ONE XCD, i.e. behind one L2
   int tile_m, tile_n;
   {
@@ -85,10 +93,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
 
   // ---- loaders ---------------------------------------------------------------------------------
   const int kq = tid & 7, lrow = tid >> 3;
-  int aoff0[MI], aoff1[MI], ssoff[MI];
-  int edge[MI];          // S2: bit 0 = output row 0 (tap row ky = 0 is padding), bit 1 = output column 0 (kx = 0 is padding)
+  int aoff0[MQ], aoff1[MQ], ssoff[MQ];
+  int edge[MQ];          // S2: bit 0 = output row 0 (tap row ky = 0 is padding), bit 1 = output column 0 (kx = 0 is padding)
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int i = 0; i < MQ; ++i) {
     const int m = tile_m * BM + lrow + 32 * i;
     if constexpr (S2) {
       const int b = m / HoWo, r = m - b * HoWo;
@@ -103,11 +111,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
     }
     ssoff[i] = ((m / HoWo) * Cin + kq * 4) * 2;
   }
-  const bf16x8* bq = reinterpret_cast<const bf16x8*>(p.w_split) + ((size_t)(tile_n * 4 + wave) * total + it0) * (6 * 64) + lane;
+  const bf16x8* bq = reinterpret_cast<const bf16x8*>(p.w_split) + ((size_t)(tile_n * NWN + wn) * total + it0) * (6 * 64) + lane;
 
-  f32x4 ra[3][MI];
+  f32x4 ra[3][MQ];
   bf16x8 rb[3][6];
-  f32x4 ssa[MI], ssb[MI];
+  f32x4 ssa[MQ], ssb[MQ];
   int pad[3] = {0, 0, 0};       // S2: bit i = row i of register set s is padding (its staged value is zero)
   auto load_a = [&](int s, int it) {
     if constexpr (S2) {
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
       const int tapedge = (ky == 0 ? 1 : 0) | (kx == 0 ? 2 : 0);
       int pm = 0;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
+      for (int i = 0; i < MQ; ++i) {
         const bool out = (edge[i] & tapedge) != 0;
         ra[s][i] = *reinterpret_cast<const f32x4*>(p.src0 + aoff0[i] + (out ? (chunk << 5) : off));
         pm |= out ? (1 << i) : 0;
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
     const bool second = c >= p.C0;          // wave-uniform
     const float* sp = second ? p.src1 : p.src0;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) ra[s][i] = *reinterpret_cast<const f32x4*>(sp + (second ? aoff1[i] : aoff0[i]) + c);
+    for (int i = 0; i < MQ; ++i) ra[s][i] = *reinterpret_cast<const f32x4*>(sp + (second ? aoff1[i] : aoff0[i]) + c);
   };
   auto load_b = [&](int s, int rel) {
     const bf16x8* q = bq + (size_t)rel * (6 * 64);
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
     if constexpr (ACT) {
       const int c2 = it << 6;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
+      for (int i = 0; i < MQ; ++i) {
         const float* q = p.ss + ssoff[i] + c2;
         ssa[i] = *reinterpret_cast<const f32x4*>(q);
         ssb[i] = *reinterpret_cast<const f32x4*>(q + 4);
@@ -148,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
     }
   };
   // LDS write position of this thread's quad: K = 16 step kq >> 2, lane slot lrow + 32 * ((kq >> 1) & 1), 8-byte half kq & 1
-  const int wbase = (kq >> 2) * (MI * 3 * FRAG) + (lrow + 32 * ((kq >> 1) & 1)) * 16 + (kq & 1) * 8;
+  const int wbase = (kq >> 2) * (MQ * 3 * FRAG) + (lrow + 32 * ((kq >> 1) & 1)) * 16 + (kq & 1) * 8;
   auto stage_a = [&](int s, int stage) {
     char* A = smem + stage * STAGE + wbase;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int i = 0; i < MQ; ++i) {
       f32x4 v = ra[s][i];
       if constexpr (S2) { if (pad[s] & (1 << i)) v = f32x4{0.f, 0.f, 0.f, 0.f}; }
       if constexpr (ACT) {
@@ -187,11 +195,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   // reads the NEXT step's first fragments -- the LDS round trip and the barrier skew run under the last third of the MFMAs instead of
   // in front of the next step's first one.
   // Slices per staged quad (4 floats): affine | per pair: h, first residuals, m, second residuals + l | the three LDS writes.
-  constexpr int NSQ = 10, NSL = NSQ * MI, NMF = 12 * MI, NBAR = 8 * MI;
+  constexpr int NSQ = 10, NSL = NSQ * MQ, NMF = 12 * MI, NBAR = 8 * MI;
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // smallest terms first (mfma_split6's order)
   bf16x8 a0[MI][3];
   auto read_a0 = [&](int stage) {
-    const char* Ar = smem + stage * STAGE + lane * 16;
+    const char* Ar = smem + stage * STAGE + lane * 16 + wm * (MI * 3 * FRAG);      // this wave's m blocks: wm * MI ...
 #pragma unroll
     for (int m = 0; m < MI; ++m)
 #pragma unroll
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   auto step = [&](int s0, int s1, int s2, int i) {
     const int stage = i & 1;
     const int i2 = min(i + 2, nsteps - 1);
-    const char* Ar = smem + stage * STAGE + lane * 16;
+    const char* Ar = smem + stage * STAGE + lane * 16 + wm * (MI * 3 * FRAG);
     char* Aw = smem + (stage ^ 1) * STAGE + wbase;
     bf16x8 a1[MI][3];
 #ifdef SR3_G1_ABL      // timing-only A/B builds (tools/build_variant.sh): 1 = every step re-reads B of step 0 (L1-hot), 2 = no staging
@@ -210,9 +218,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
     load_a(s2, it0 + i2); load_b(s2, i2);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 v[MI];
-    float r[MI][4];
-    unsigned hh[MI][2], mm[MI][2], ll[MI][2];
+    f32x4 v[MQ];
+    float r[MQ][4];
+    unsigned hh[MQ][2], mm[MQ][2], ll[MQ][2];
     auto slice = [&](int sl) {
 #ifdef SR3_G1_ABL
       if (SR3_G1_ABL & 2) return;
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
 #pragma unroll
         for (int mb = 0; mb < MI; ++mb)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) a1[mb][pl] = *reinterpret_cast<const bf16x8*>(Ar + ((MI + mb) * 3 + pl) * FRAG);
+          for (int pl = 0; pl < 3; ++pl) a1[mb][pl] = *reinterpret_cast<const bf16x8*>(Ar + ((MQ + mb) * 3 + pl) * FRAG);
       }
       if (n < NBAR - 1) {
 #pragma unroll
@@ -301,14 +309,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm1x1_split(const ConvParams p) {
   // ---- epilogue: D layout of the 32x32 MFMA: reg r of lane l -> row (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col l & 31 ----------
   const bool direct = p.ksplit == 1;
   float* dst = direct ? p.out : p.partial + (size_t)blockIdx.y * M * p.Cout;
-  const int n = tile_n * 128 + wave * 32 + (lane & 31);
+  const int n = tile_n * (32 * NWN) + wn * 32 + (lane & 31);
   float bn = 0.f;
   if (direct && p.bias) bn = p.bias[n];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int mbase = tile_m * BM + 32 * i + 8 * g;       // wave-uniform; an 8-row group never straddles an image (HoWo % 32 == 0)
+      const int mbase = tile_m * BM + 32 * (wm * MI + i) + 8 * g;       // wave-uniform; an 8-row group never straddles an image (HoWo % 32 == 0)
       float fb = bn;
       if (direct && p.film) fb += p.film[(size_t)(mbase / HoWo) * p.film_stride + n];
 #pragma unroll
@@ -330,13 +338,15 @@ bool gemm1x1_s2(const ConvParams& p) {      // the 3x3 stride-2 pad-1 form (Down
 }
 bool gemm1x1_fits(const ConvParams& p, int mi) {
   const long M = (long)p.B * p.Ho * p.Wo;
-  return ((p.ksize == 1 && p.stride == 1) || gemm1x1_s2(p)) && p.ups == 0 && (p.Cout & 127) == 0 && p.C0 > 0 && (p.C0 & 31) == 0 && (p.C1 & 31) == 0 &&
+  return ((p.ksize == 1 && p.stride == 1) || gemm1x1_s2(p)) && p.ups == 0 && (p.Cout & 63) == 0 && p.C0 > 0 && (p.C0 & 31) == 0 && (p.C1 & 31) == 0 &&
          M % (32 * mi) == 0 && ((p.Ho * p.Wo) & 31) == 0 && (p.act == 0 || p.act == 1) && p.drop_thresh == 0 && !p.x2_w;
 }
 
 // rows of the tile: 64 (two m blocks per wave), or 32 where 64 would leave workgroup slots empty -- 512 slots = two workgroups per CU; the
 // N = 512 layers at 16 x 16 (M = 4096) give 256 tiles of 64 rows: one wave per SIMD, nothing to overlap with; 512 tiles of 32 rows fill them
+int gemm1x1_cols(const ConvParams& p) { return (p.Cout & 127) ? 64 : 128; }      // the 2 x 2 wave arrangement (WM = 2) where Cout % 128 != 0
 int gemm1x1_rows(const ConvParams& p) {
+  if (p.Cout & 127) return 64;
 #ifdef SR3_G1_NO32
   return 64;
 #elif defined(SR3_G1_ALL32)
@@ -356,10 +366,11 @@ int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   if (!gemm1x1_fits(p, mi) || !p.w_split) { set_error("conv: the 1x1 GEMM kernel (tile 22) does not fit this problem"); return SR3_E_UNSUPPORTED; }
   if (p.act == 1 && !p.ss) { set_error("conv: act needs ss"); return SR3_E_BADARG; }
   const int M = p.B * p.Ho * p.Wo;
-  mi = gemm1x1_rows(p) / 32;
-  dim3 grid((M / (32 * mi)) * (p.Cout / 128), p.ksplit);
+  const int rows = gemm1x1_rows(p), cols = gemm1x1_cols(p);
+  mi = rows / 32;
+  dim3 grid((M / rows) * (p.Cout / cols), p.ksplit);
   const int smem = 2 * 2 * mi * 3 * 1024;
-  static std::atomic<uint64_t> done[6];
+  static std::atomic<uint64_t> done[9];
   auto go = [&](auto kern, std::atomic<uint64_t>& d) -> int {
     if (int rc = ensure_max_lds(reinterpret_cast<const void*>(kern), smem, d)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
@@ -368,8 +379,12 @@ int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st) {
   };
   // (MI = 4, a 128-row tile with half the weight traffic per row, was built and dropped: at 256 registers it spills, and the weight
   // traffic is not what bounds this kernel -- profiles/r06_gemm1x1.txt)
+  if (p.ksize == 3 && p.act) { set_error("conv: the stride-2 form of the GEMM kernel takes no activation"); return SR3_E_UNSUPPORTED; }
+  if (cols == 64) {      // 64 x 64 tile, waves 2 x 2 (one m block per wave)
+    if (p.ksize == 3) return go(k_gemm1x1_split<1, false, true, 2>, done[6]);
+    return p.act ? go(k_gemm1x1_split<1, true, false, 2>, done[7]) : go(k_gemm1x1_split<1, false, false, 2>, done[8]);
+  }
   if (p.ksize == 3) {
-    if (p.act) { set_error("conv: the stride-2 form of the GEMM kernel takes no activation"); return SR3_E_UNSUPPORTED; }
     return mi == 2 ? go(k_gemm1x1_split<2, false, true>, done[4]) : go(k_gemm1x1_split<1, false, true>, done[5]);
   }
   if (mi == 2) return p.act ? go(k_gemm1x1_split<2, true>, done[0]) : go(k_gemm1x1_split<2, false>, done[1]);

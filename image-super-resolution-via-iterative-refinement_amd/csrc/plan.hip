@@ -445,6 +445,8 @@ struct Builder {
     // read by conv_pick / conv_forward only when the conv lands on the im2col kernel; the 9-tap layers with Cout <= 64 (Downsample
     // of the first level) stay on the fp32 MFMA, which is faster there (67 vs 81 us in the forward)
     c.igemm_split = (P->gemm_split && !(ksize == 3 && Cout <= 64)) ? 1 : 0;
+    // (... unless the plain GEMM kernel takes the layer on its 64-column tile: plan options gemm2 + gemm_s2 + gemm_n64, below)
+    if (P->gemm_split && P->gemm2 && P->gemm_s2 && P->gemm_n64 && ksize == 3 && stride == 2 && P->wsplit_of.count(w) && gemm1x1_fits(c, 2)) c.igemm_split = 1;
     conv_pick(c, o.tile_cfg, o.ksplit);
     if (P->gemm_tile >= 1 && P->gemm_tile <= 4 && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->tile_cfg == 0) {
       o.tile_cfg = P->gemm_tile; o.ksplit = P->ksplit;       // A/B knob: one im2col tile for every conv of that kernel
@@ -452,7 +454,7 @@ struct Builder {
     }
     if (c.igemm_split && o.tile_cfg >= 1 && o.tile_cfg <= 4 && P->gemm2 && P->tile_cfg == 0 && P->gemm_tile == 0 && P->wsplit_of.count(w)) {
       // plan option gemm2: 1x1 stride-1 convs -- and Downsample's 3x3 stride-2 ones -- the plain GEMM kernel fits (gemm1x1.hip)
-      if (gemm1x1_fits(c, 2) && (ksize == 1 || P->gemm_s2)) {
+      if (gemm1x1_fits(c, 2) && (ksize == 1 || P->gemm_s2) && (!(Cout & 127) || P->gemm_n64)) {
         o.tile_cfg = 22; o.ksplit = P->ksplit;
         conv_pick(c, o.tile_cfg, o.ksplit);
         o.has_wsplit = true; o.wsplit_off = P->wsplit_of[w];
@@ -704,7 +706,7 @@ void layout_derived(sr3_plan* P) {
   if (P->gemm_split && (P->gemm_wpre || P->gemm2)) {
     auto regw = [&](size_t w, int Cout, int taps, int Cin) {
       if (Cin & 3) return;
-      if (!P->gemm_wpre && ((taps != 1 && !(taps == 9 && P->gemm_s2)) || (Cout & 127) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take (1x1; Downsample's 3x3 stride 2)
+      if (!P->gemm_wpre && ((taps != 1 && !(taps == 9 && P->gemm_s2)) || (Cout & (P->gemm_n64 ? 63 : 127)) || (Cin & 31))) return;     // gemm2 alone: only what gemm1x1.hip can take (1x1; Downsample's 3x3 stride 2)
       P->wsplits.push_back({w, Cout, taps, Cin, dcur});
       P->wsplit_of[w] = dcur;
       dcur += igemm_wsplit_floats(Cout, taps, Cin);
@@ -714,7 +716,7 @@ void layout_derived(sr3_plan* P) {
         if (L.kind == 1) {
           if (L.res.has_rc) regw(L.res.rc_w, L.res.cout, 1, L.res.cin);
           if (L.res.attn) { regw(L.res.qkv_w, 3 * L.res.cout, 1, L.res.cout); regw(L.res.ao_w, L.res.cout, 1, L.res.cout); }
-        } else if (L.kind == 2 && L.cout > 64) {
+        } else if (L.kind == 2 && (L.cout > 64 || (P->gemm2 && P->gemm_s2 && P->gemm_n64 && L.cout == 64))) {
           regw(L.w, L.cout, 9, L.cin);
         }
       }
@@ -1175,6 +1177,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   else if (!strcmp(key, "gemm2")) slot = &plan->gemm2;
   else if (!strcmp(key, "gemm_s2")) slot = &plan->gemm_s2;
   else if (!strcmp(key, "fork_side")) slot = &plan->fork_side;
+  else if (!strcmp(key, "gemm_n64")) slot = &plan->gemm_n64;
   else if (!strcmp(key, "fold_fuse")) slot = &plan->fold_fuse;
   else if (!strcmp(key, "gemm_tile")) slot = &plan->gemm_tile;
   else if (!strcmp(key, "wino2")) slot = &plan->wino2;
@@ -1192,7 +1195,7 @@ int sr3_plan_set_option(sr3_plan* plan, const char* key, int value) {
   plan->train_batch = -1;
   // which convs read transformed filters depends on these: a forward must not run on filters prepared for another choice
   if (slot == &plan->winograd || slot == &plan->tile_cfg || slot == &plan->split_bf16) plan->derived_from = nullptr;
-  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre || slot == &plan->gemm2 || slot == &plan->gemm_s2) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
+  if ((slot == &plan->wino_split || slot == &plan->gemm_split || slot == &plan->gemm_wpre || slot == &plan->gemm2 || slot == &plan->gemm_s2 || slot == &plan->gemm_n64) && prev != value) layout_derived(plan);     // (the buffer has to be re-bound and re-prepared)
   return prev;
 }
 int sr3_plan_num_taps(sr3_plan* plan) { return plan ? (int)plan->taps.size() : 0; }

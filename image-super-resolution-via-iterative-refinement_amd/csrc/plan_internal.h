@@ -137,6 +137,8 @@ struct sr3_plan {
                              // (round 6; 27 of the 33 launches of the C2 forward: 1.09 -> 0.80 ms, profiles/r06_gemm1x1.txt).  0: the im2col kernel
   int gemm_s2 = 1;           // ... and Downsample's 3x3 stride-2 convs on that kernel's stride-2 form (needs gemm2; Cout % 128 == 0; last session of
                              // round 6: the three launches of the C2 forward 171 -> 118 us)
+  int gemm_n64 = 1;          // ... and the layers with Cout % 128 != 0 (Cout % 64 == 0: the res_convs of the 128 x 128 level, Downsample 64 -> 64) on
+                             // its 64-column tile (waves 2 x 2); 0: they keep the im2col kernel
   int fork_side = 0;         // res_conv (and the embedding MLP) on a side stream beside block1's conv: see Op::side_id; A/B knob
   hipStream_t side_stream = nullptr;          // fork_side: created at the first forked forward, on the device current then
   std::vector<hipEvent_t> fork_ev, join_ev;   // one pair per forked op of the compiled forward

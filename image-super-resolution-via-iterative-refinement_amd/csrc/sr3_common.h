@@ -220,6 +220,7 @@ size_t igemm_wsplit_floats(int Cout, int taps, int Cin);
 int igemm_split_weights(const float* w, int Cout, int taps, int Cin, float* out, hipStream_t st);
 // 1x1 stride-1 convs as a plain GEMM on the split arithmetic (gemm1x1.hip; tile_cfg 22: 64 x 128 tile, mi = 2; needs w_split)
 bool gemm1x1_fits(const ConvParams& p, int mi);
+int gemm1x1_cols(const ConvParams& p);      // 128, or 64 (waves 2 x 2) where Cout % 128 != 0
 int gemm1x1_forward(const ConvParams& p, int mi, hipStream_t st);
 int gemm1x1_rows(const ConvParams& p);      // 64, or 32 where 64-row tiles would leave workgroup slots empty
 // profiling aid: when non-null, conv_forward records this event between the GEMM kernel and the

@@ -61,7 +61,7 @@ int dgrad_conv(const TrainCtx& X, const float* g, int Cg, int H, int W, int ksiz
   c.igemm_split = (X.P->gemm_split && !(ksize == 3 && c.Cout <= 64)) ? 1 : 0;
   // 1x1: the plain GEMM kernel where it fits (plan option gemm2; gemm1x1.hip), its pre-split weights derived from the transposed filters
   // into the region the Winograd data gradients use for theirs
-  if (c.igemm_split && X.P->gemm2 && gemm1x1_fits(c, 2) && igemm_wsplit_floats(Cin, 1, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
+  if (c.igemm_split && X.P->gemm2 && gemm1x1_fits(c, 2) && (!(c.Cout & 127) || X.P->gemm_n64) && igemm_wsplit_floats(Cin, 1, Cg) * sizeof(float) <= X.P->t_wu_bytes) {
     float* ws_ = X.at<float>(X.P->t_wu_off);
     rc = igemm_split_weights(wt, Cin, 1, Cg, ws_, X.st);
     if (rc) return rc;

@@ -99,7 +99,7 @@ int sr3_plan_op_side(sr3_plan* plan, int batch, int index, int* side_id, int* wa
 /* algorithmic FLOPs (contractions only) of one forward for `batch` images */
 double sr3_plan_forward_flops(sr3_plan* plan, int batch);
 /* tuning knobs: key in {"fuse_stats", "fuse_res", "tile_cfg", "ksplit", "keep_all", "split_bf16", "winograd",
- * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_s2", "fork_side", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
+ * "wino_split", "wino_split8", "wino2", "gemm_split", "gemm2", "gemm_s2", "gemm_n64", "fork_side", "gemm_wpre", "gemm_tile", "fold_fuse", "wgrad_split", "attn_split",
  * "loss_l2"};
  * returns previous value.
  * wino_split (default 1): the Winograd convolutions that run on the kernel's one-image tile (maps >= 16x16) use its 3 x bf16
@@ -128,6 +128,9 @@ double sr3_plan_forward_flops(sr3_plan* plan, int batch);
  *   activation, even maps) run on the same kernel's stride-2 form (also reported as tile 22): the GEMM's k-steps walk (32-channel
  *   chunk, tap), the A row of a tap is the NHWC row of the shifted input pixel, padding rows are zeroed where they are staged;
  *   54 bytes per weight in the derived buffer.  0: the im2col kernel (tile 16).
+ * gemm_n64 (default 1, round 6; needs gemm2): the layers with Cout % 128 != 0 and Cout % 64 == 0 (res_conv of the first resolution level,
+ *   Downsample 64 -> 64 with gemm_s2, data gradients towards 64 / 192 channels) on the same kernel's 64 x 64 tile, its four waves 2 x 2.
+ *   0: they keep the im2col kernel (tile 16; Downsample 64 -> 64 its fp32 form, tile 2).
  * fork_side (default 0; A/B knob, inference plans): every unsplit res_conv is emitted in front of its block's first conv and launched
  *   on a side stream the plan owns (fork / join by events: a parallel branch once the forward is captured into a graph), block2's conv
  *   waits for it; the embedding MLP runs beside the input conv the same way.  Results are bit-identical (same kernels, same operands).
@@ -296,7 +299,7 @@ int sr3_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * the same with the weights pre-split into bf16 planes in MFMA fragment order and read straight from global memory (plan option
  * gemm_wpre, default off: a plan keeps the planes in its derived buffer; this entry point derives them into `scratch`; results
  * are bit-identical to 14-17); 22 = the plain GEMM kernel of gemm1x1.hip (what plan options gemm2 / gemm_s2 -- default on -- select: 1x1
- * stride 1, or 3x3 stride 2 with one source, act 0 and an even map; no upsampling, Cout % 128 == 0, C0 and C1 % 32 == 0,
+ * stride 1, or 3x3 stride 2 with one source, act 0 and an even map; no upsampling, Cout % 64 == 0, C0 and C1 % 32 == 0,
  * B * Ho * Wo % 64 == 0, Ho * Wo % 32 == 0, act 0 | 1; anything else is refused with "does not fit"; same pre-split weights as
  * 18-21, derived into `scratch`).
  * scratch: split-K slabs (+ the Winograd filters for tile_cfg 11-13, the pre-split weights for 18-22), sized by

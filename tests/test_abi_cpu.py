@@ -177,14 +177,20 @@ def test_plan_launch_list_no_gpu():
     dconvs = [o for o in wops if o['kind'] == 50]
     for o in dconvs:
         s2 = o['ksize'] == 3 and o['stride'] == 2
-        assert (o['tile_cfg'] == 22) == (((o['ksize'] == 1 and o['stride'] == 1) or s2) and o['cout'] % 128 == 0), o
+        # (plan option gemm_n64: Cout % 128 != 0 -- the Cout = 64 layers of the 128 x 128 level -- on the kernel's 64 x 64 tile, waves 2 x 2)
+        assert (o['tile_cfg'] == 22) == (((o['ksize'] == 1 and o['stride'] == 1) or s2) and o['cout'] % 64 == 0), o
         if o['tile_cfg'] == 22:        # split-K only below 128 workgroups; tile rows 64, or 32 where 64-row tiles leave slots empty (gemm1x1_rows)
             M = 16 * o['h_out'] * o['w_out']
-            rows = 64 if (M // 64) * (o['cout'] // 128) >= 384 else (32 if (s2 or M <= 1024 or o['cin'] <= 512) else 64)
+            cols = 128 if o['cout'] % 128 == 0 else 64
+            rows = 64 if (cols == 64 or (M // 64) * (o['cout'] // 128) >= 384) else (32 if (s2 or M <= 1024 or o['cin'] <= 512) else 64)
             # (the stride-2 form: long K on small maps -- it splits whenever its tiles do not fill the 512 workgroup slots)
-            assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // 128) < (512 if s2 else 128)), o
-    assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 30
-    assert [(o['cin'], o['h_out'], o['ksplit']) for o in dconvs if o['tile_cfg'] == 22 and o['ksize'] == 3] == [(128, 32, 1), (256, 16, 2), (512, 8, 4)]
+            assert (o['ksplit'] > 1) == ((M // rows) * (o['cout'] // cols) < (512 if s2 else 128)), o
+    assert sum(1 for o in dconvs if o['tile_cfg'] == 22) == 34
+    assert [(o['cin'], o['h_out'], o['ksplit']) for o in dconvs if o['tile_cfg'] == 22 and o['ksize'] == 3] == [(64, 64, 1), (128, 32, 1), (256, 16, 2), (512, 8, 4)]
+    p.set_option('gemm_n64', 0)        # plan option gemm_n64 = 0: the four Cout = 64 layers back on the im2col kernel (Downsample 64 -> 64 on its fp32 form)
+    nops = [o for o in p.op_list(16) if o['kind'] == 50]
+    assert [(a['tile_cfg'], b['tile_cfg'], a['cout']) for a, b in zip(dconvs, nops) if a['tile_cfg'] != b['tile_cfg']] == [(22, 2, 64)] + [(22, 16, 64)] * 3
+    p.set_option('gemm_n64', 1)
     # plan option fork_side (default 0): every unsplit res_conv is emitted in front of its block's first conv and marked for the side stream,
     # block2's conv -- which adds it as its residual -- waits for it; the embedding MLP beside the input conv, joined by the first FiLM conv.
     # Same ops, same flops; nothing is marked in the default plan
@@ -207,7 +213,7 @@ def test_plan_launch_list_no_gpu():
     assert p.op_list(16) == wops
     p.set_option('gemm_s2', 0)         # plan option gemm_s2 = 0: the three Downsample convs back on the im2col split tile, nothing else moves
     sops = [o for o in p.op_list(16) if o['kind'] == 50]
-    assert [(a['tile_cfg'], b['tile_cfg']) for a, b in zip(dconvs, sops) if a['tile_cfg'] != b['tile_cfg']] == [(22, 16)] * 3
+    assert [(a['tile_cfg'], b['tile_cfg']) for a, b in zip(dconvs, sops) if a['tile_cfg'] != b['tile_cfg']] == [(22, 2)] + [(22, 16)] * 3
     p.set_option('gemm_s2', 1)
     nbytes_gemm2 = int(p.lib.sr3_plan_derived_bytes(p.handle))
     p.set_option('gemm2', 0)           # the rest of this test walks the im2col options with gemm2 off
@@ -215,7 +221,7 @@ def test_plan_launch_list_no_gpu():
     wops0 = p.op_list(16)
     assert len(wops0) == p.num_ops(16) == 168
     for a, b in zip([o for o in wops if o['kind'] == 50], [o for o in wops0 if o['kind'] == 50]):
-        assert a['flops'] == b['flops'] and (a['tile_cfg'] == b['tile_cfg'] or (a['tile_cfg'] == 22 and b['tile_cfg'] == 16))
+        assert a['flops'] == b['flops'] and (a['tile_cfg'] == b['tile_cfg'] or (a['tile_cfg'] == 22 and b['tile_cfg'] in (16, 2)))     # (2: Downsample 64 -> 64 on the fp32 im2col tile)
     wops = wops0
     wconvs = [o for o in wops if o['kind'] == 50]
     for o in wconvs:
@@ -401,10 +407,14 @@ def test_round5_plan_options_no_gpu():
         assert p.set_option(key, 0) == 1 and p.op_list(16) == ops
         assert p.set_option(key, 1) == 0
     # gemm_wpre (default 0: the weights pre-split in MFMA fragment order, read straight from global memory, measured slower): 16 <-> 20
-    assert sorted(set(o['tile_cfg'] for o in ops if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [16]
+    # (since gemm_s2 / gemm_n64 every 1x1 and stride-2 conv of this network runs the plain GEMM kernel, tile 22: the im2col split tiles
+    # appear with gemm2 = 0)
+    assert sorted(set(o['tile_cfg'] for o in ops if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == []
+    assert p.set_option('gemm2', 0) == 1
+    assert sorted(set(o['tile_cfg'] for o in p.op_list(16) if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [16]
     assert p.set_option('gemm_wpre', 1) == 0
     assert sorted(set(o['tile_cfg'] for o in p.op_list(16) if o['kind'] == 50 and 14 <= o['tile_cfg'] <= 21)) == [20]
-    assert p.set_option('gemm_wpre', 0) == 1 and p.op_list(16) == ops
+    assert p.set_option('gemm_wpre', 0) == 1 and p.set_option('gemm2', 1) == 0 and p.op_list(16) == ops
     # wino2 (round 6): maps >= 16 x 16 between the two-workgroups-per-CU kernel (tile 13) and the 8-wave kernel (tile 12)
     assert any(o['tile_cfg'] == 13 for o in ops) and p.set_option('wino2', 0) == 1
     assert not any(o['tile_cfg'] == 13 for o in p.op_list(16)) and p.set_option('wino2', 1) == 0 and p.op_list(16) == ops

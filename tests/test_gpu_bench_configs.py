@@ -138,9 +138,9 @@ def test_c2_batch16_wino_split_gate_and_exact_fp32_plan():
     netG.denoise_fn.plan.set_option('attn_split', 1)
     cfgs = _cfgs(netG, B)
     assert (13, 1) in cfgs and (13, 2) in cfgs and (12, 8) in cfgs and not any(t == 11 for t, k in cfgs), sorted(set(cfgs))
-    # gemm_split: the Cout = 64 res_convs on the im2col split tile, everything else of that family on the plain GEMM kernel (gemm2, gemm_s2:
-    # the Downsample convs of the 16 x 16 / 8 x 8 outputs under split-K 2 / 4)
-    assert (16, 1) in cfgs and (22, 1) in cfgs and (22, 2) in cfgs and (22, 4) in cfgs and not any(t in (1, 3, 4) for t, _ in cfgs), sorted(set(cfgs))
+    # gemm_split: every 1x1 and stride-2 conv on the plain GEMM kernel (gemm2, gemm_s2, gemm_n64: the Downsample convs of the 16 x 16 / 8 x 8
+    # outputs under split-K 2 / 4); no im2col tile is left in this network's default plan
+    assert (22, 1) in cfgs and (22, 2) in cfgs and (22, 4) in cfgs and not any(1 <= t <= 4 or 14 <= t <= 21 for t, _ in cfgs), sorted(set(cfgs))
     e_split = G.assert_close(netG.denoise_fn(x.to(d), lvl.to(d)).cpu(), ref, what='C2 batch 16 eps (wino_split)')
     print('C2 batch 16: eps max abs err vs the CPU oracle: fp32 Winograd plan %.2e, wino_split plan %.2e (|ref|max %.2f)'
           % (e_fp32, e_split, ref.abs().max().item()))

@@ -351,12 +351,15 @@ GEMM_SPLIT_CASES = [
     ('down_128', 1, 64, 0, 128, 128, 64, 3, 2, 0, 0, False, False, True),
     ('down_16', 2, 512, 0, 16, 16, 512, 3, 2, 0, 0, False, False, True),
     ('down_rect_32x64', 2, 128, 0, 32, 64, 256, 3, 2, 0, 0, False, False, True),
+    ('n64_affine_320', 2, 96, 32, 16, 32, 320, 1, 1, 0, 1, True, True, True),        # Cout % 128 != 0: the 64 x 64 tile, with every epilogue term
+    ('down_64to64', 1, 64, 0, 64, 64, 64, 3, 2, 0, 0, False, False, True),
 ]
 
 
 def _gemm1x1_fits(k, stride, Cout, C1=0, act=0):
-    """What gemm1x1.hip takes (tile 22): 1x1 stride 1, or Downsample's bare 3x3 stride 2 (one source, no activation); Cout % 128 == 0."""
-    return Cout % 128 == 0 and ((k == 1 and stride == 1) or (k == 3 and stride == 2 and C1 == 0 and act == 0))
+    """What gemm1x1.hip takes (tile 22): 1x1 stride 1, or Downsample's bare 3x3 stride 2 (one source, no activation); Cout % 64 == 0
+    (Cout % 128 != 0: its 64 x 64 tile, waves 2 x 2)."""
+    return Cout % 64 == 0 and ((k == 1 and stride == 1) or (k == 3 and stride == 2 and C1 == 0 and act == 0))
 
 
 @pytest.mark.parametrize('tile,ksplit', [(14, 1), (16, 1), (15, 2), (18, 1), (19, 1), (20, 1), (21, 1), (19, 2), (20, 3), (22, 1), (22, 2), (22, 0), (0, 0)])
