@@ -152,7 +152,9 @@ def test_committed_profile_summaries_cover_the_kernels_bench_reports():
     with open(os.path.join(ROOT, 'profiles', bench.PROFILE_ROUND + '_sq_counters.json')) as f:
         sq = json.load(f)
     for sym in ('sr3::k_conv3x3_wino2<0>', 'sr3::k_conv3x3_wino<0, false, false, false>',
-                'sr3::k_conv_igemm<64, 64, 1, 1>', 'sr3::k_conv_igemm<64, 64, 1, 0>',
+                'sr3::k_gemm1x1_split<2, true, false, 1>', 'sr3::k_gemm1x1_split<1, false, true, 1>', 'sr3::k_gemm1x1_split<1, false, false, 2>',
+                'sr3::k_conv_igemm<64, 64, 1, 0>',      # (the plain GEMM kernel: qkv, its stride-2 form, its 64 x 64 tile -- no im2col split launch
+                                                        #  is left in the default plan since the last session of round 6; the fp32 plan keeps the im2col kernel)
                 'sr3::k_conv3x3_wino<0, false, true, true>', 'sr3::k_attention_v2<2, 2, true>'):
         assert 5e6 < traffic[sym]['hbm_bytes_per_launch'] < 1e9, (sym, traffic.get(sym))
         assert 0.05 < sq[sym]['mfma_busy'] < 1.0, (sym, sq.get(sym))
