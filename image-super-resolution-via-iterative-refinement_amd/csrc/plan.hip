@@ -529,7 +529,7 @@ struct Builder {
     return out;
   }
   // fork_side: is res_conv its own launch in this block (block2's conv has no fused 1x1 segment)?  Same rule as can_fuse_x2, asked before h1 exists
-  bool wino_fits_block2(int x0, const ResLayer& R) {
+  bool res_conv_is_own_launch(int x0, const ResLayer& R) {
     if (!P->fuse_res) return true;
     ConvParams c;
     memset(&c, 0, sizeof(c));
@@ -565,7 +565,7 @@ struct Builder {
     // conv -- and launched on the side stream; block2's conv, which adds it as its residual, waits for it.  Only unsplit: a split-K res_conv
     // would share the slab region with block1's conv.  (The fold stays where fold_fuse looks for it: behind the op that completes x.)
     int r_side = -1, r_id = -1;
-    if (R.has_rc && P->fork_side && !train && wino_fits_block2(x0, R)) {
+    if (R.has_rc && P->fork_side && !train && res_conv_is_own_launch(x0, R)) {
       r_side = conv(x0, x1, R.cout, 1, 1, 0, 0, R.rc_w, true, R.rc_b, -1, -1, -1, false);
       if (ops.back().kind == OP_CONV && ops.back().ksplit == 1) { r_id = n_side++; ops.back().side_id = r_id; }
     }
