@@ -171,7 +171,19 @@ __global__ __launch_bounds__(256) void k_rows_fold(const ConvParams p, const Fol
   __shared__ double chs[2 * 128];       // per-channel {sum, sumsq} of the group, concat order
   __shared__ float mrs[2];
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / f.groups, g = blockIdx.x - b * f.groups;
+  // XCD-aware order (last session of round 6): workgroups are dealt to the 8 XCDs round-robin, and neighbouring groups of an image share
+  // 128-byte lines of every row (a group of 16 channels is half a line) -- consecutive (image, group) pairs go to ONE XCD, behind one L2
+#ifdef SR3_FOLD_NO_XCD
+  const int lin = blockIdx.x;
+#else
+  int lin;
+  {
+    const int nwg = gridDim.x, w = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+  }
+#endif
+  const int b = lin / f.groups, g = lin - b * f.groups;
   const int cpg = f.Ctot / f.groups;
   const int glo = g * cpg, ghi = glo + cpg;
   const int a_lo = max(glo, f.c_off) - f.c_off, a_hi = min(ghi, f.c_off + C) - f.c_off;      // this tensor's channels of the group
